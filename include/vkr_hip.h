@@ -1,0 +1,235 @@
+/*
+ * vkr_hip.h -- C ABI of libvkr_hip.so: VulkanRenderer's screen-space shading path on MI355X.
+ *
+ * The reference (a C# / Vulkan renderer) has no native seam of its own for this path: its C#
+ * pass objects call straight into libvulkan through Silk.NET.  The seam bound here is the one
+ * its pass interface implies -- one entry point per render pass the reference records, taking
+ * the same parameter blocks (SceneInfo / LightInfo, byte for byte) and the same images
+ * (tight row-major RGBA16F / D32F).  Each declaration cites the reference code it replaces.
+ *
+ * Two layers:
+ *   layer 1  vkr_shade / vkr_bloom_blur / ...   stateless passes over caller-owned DEVICE memory,
+ *            launched on a caller-supplied HIP stream (NULL = the default stream); asynchronous.
+ *   layer 2  vkr_create / vkr_end_frame / ...   a renderer object that owns its device images and
+ *            takes HOST pointers; this is what a P/Invoke binding calls.
+ *
+ * Conventions: every function returns 0 (VKR_OK) or a negative VKR_ERR_* code and records a
+ * message retrievable with vkr_last_error() (thread-local).  No function is thread-safe with
+ * respect to the same vkr_ctx; different contexts may be used from different threads.
+ * Images: RGBA16F = 4 x uint16 (binary16) per texel, RG16F = 2 x uint16, D32F = float,
+ * RGBA8 = 4 x uint8; rows are tightly packed, row 0 is the top row of the frame.
+ * Cubes: 6 faces in the order +X,-X,+Y,-Y,+Z,-Z, each face row-major.
+ */
+#ifndef VKR_HIP_H
+#define VKR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define VKR_EXPORT __attribute__((visibility("default")))
+#else
+#define VKR_EXPORT
+#endif
+
+#define VKR_OK 0
+#define VKR_ERR_INVALID (-1)     /* bad argument (null pointer, size <= 0, unknown enum) */
+#define VKR_ERR_HIP (-2)         /* a HIP runtime call failed; see vkr_last_error() */
+#define VKR_ERR_UNSUPPORTED (-3) /* valid request this build does not implement */
+#define VKR_ERR_ORDER (-4)       /* BeginFrame / EndFrame called out of order */
+#define VKR_ERR_NO_DEVICE (-5)   /* no gfx950 device visible */
+
+/* VulkanRenderer.cs:11-20 -- SceneInfo, explicit layout, 240 bytes.  Matrices are the 16 floats
+ * of Silk.NET's row-major Matrix4X4<float> in memory order. */
+typedef struct VkrSceneInfo {
+    float camera_view[16];        /* offset   0 */
+    float camera_projection[16];  /* offset  64 */
+    float camera_position[3];     /* offset 128 */
+    float _pad0;
+    float dir_light_direction[3]; /* offset 144 */
+    float _pad1;
+    float dir_light_color[3];     /* offset 160 */
+    float _pad2;
+    float light_space_matrix[16]; /* offset 176 */
+} VkrSceneInfo;
+
+/* VulkanRenderer.cs:22-28 -- LightInfo, explicit layout, 92 bytes. */
+typedef struct VkrLightInfo {
+    float model[16];   /* offset  0: Scale(volume radius) * Translate(position), Light.cs:14 */
+    float position[3]; /* offset 64 */
+    float _pad0;
+    float color[3];    /* offset 80 */
+} VkrLightInfo;
+
+/* Which pixels a point light's draw touches (the reference rasterises a sphere mesh per light,
+ * GraphicsPipeline.cs:100-117).  Only FULLSCREEN is implemented: it equals the reference
+ * whenever the camera is inside every light volume. */
+#define VKR_COVERAGE_FULLSCREEN 0
+
+#define VKR_WRAP_REPEAT 0 /* textureSampler, VulkanHelper.cs:123-154 */
+#define VKR_WRAP_CLAMP 1  /* bloomSampler,   VulkanHelper.cs:156-187 */
+
+#define VKR_SRC_RGBA8_SRGB 0 /* Texture.cs:21 (the reference's 8-bit skybox image) */
+#define VKR_SRC_RGBA16F 1
+
+#define VKR_POST_SRGB_TARGET 1 /* store through an _SRGB target format (SCDevice.cs:655-666) */
+
+#define VKR_IRRADIANCE_SEQUENTIAL 0 /* one running sum, the shader's own order */
+#define VKR_IRRADIANCE_PHI_SLICES 1 /* per-phi partial sums added in phi order (faster) */
+
+VKR_EXPORT const char *vkr_last_error(void);
+VKR_EXPORT int32_t vkr_abi_version(void);
+/* Number of gfx950 devices visible to the process (0 if none); never fails. */
+VKR_EXPORT int32_t vkr_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Layer 1: passes over device memory
+ * ------------------------------------------------------------------------------------------ */
+
+/* Replaces the composition render pass: the fullscreen composition.frag draw
+ * (VulkanRenderer.cs:445-459) followed by one additive light.frag draw per light
+ * (VulkanRenderer.cs:479-498), over a strip of `rows` rows.  Strips are independent. */
+typedef struct VkrShadeArgs {
+    int32_t width, rows;
+    const void *albedo, *normal, *arm, *position; /* RGBA16F, rows*width texels each */
+    const void *background;                       /* RGBA16F or NULL (cleared to 0,0,0,1) */
+    VkrSceneInfo scene;
+    const VkrLightInfo *lights;                   /* device memory, n_lights entries */
+    int32_t n_lights;
+    int32_t coverage_mode;
+    const float *dir_shadow;  int32_t dir_res;    /* D32F dir_res^2 */
+    const float *cube_shadow; int32_t cube_res;   /* D32F n_lights * 6 * cube_res^2 */
+    const void *irradiance;   int32_t irr_res;    /* RGBA16F cube */
+    const void *prefilter;    int32_t pref_res;   /* RGBA16F cube (mip 0) */
+    const void *brdf_lut;     int32_t lut_res;    /* RG16F */
+    void *out_color, *out_threshold;              /* RGBA16F, rows*width texels each */
+} VkrShadeArgs;
+VKR_EXPORT int32_t vkr_shade(const VkrShadeArgs *args, void *stream);
+
+/* Replaces one bloom_blur.frag draw (VulkanRenderer.cs:504-540).  Writes `rows` output rows;
+ * output row r is centred on source row r + src_row_offset.  Taps along the blur axis wrap
+ * (REPEAT) or clamp to [clamp_lo, clamp_hi] (source row / column indices) -- a strip with halo
+ * rows passes the valid range of its source buffer. */
+typedef struct VkrBloomArgs {
+    const void *src; void *dst;  /* RGBA16F */
+    int32_t width, rows;         /* output size */
+    int32_t src_rows;            /* rows in src (== rows unless src carries halo rows) */
+    int32_t src_row_offset;
+    int32_t horizontal;          /* non-zero: blur along x (bloom pass 1) */
+    int32_t wrap;                /* VKR_WRAP_* along the blur axis */
+    int32_t clamp_lo, clamp_hi;  /* used when wrap == VKR_WRAP_CLAMP */
+} VkrBloomArgs;
+VKR_EXPORT int32_t vkr_bloom_blur(const VkrBloomArgs *args, void *stream);
+
+/* Replaces the postprocess.frag draw (VulkanRenderer.cs:544-557): hdr + bloom -> ACES ->
+ * pow(1/2.2) -> RGBA8. */
+VKR_EXPORT int32_t vkr_postprocess(const void *hdr, const void *bloom, void *out_rgba8, int32_t width, int32_t rows,
+                        int32_t flags, void *stream);
+
+/* Bloom pass 2 and the post-process draw in one kernel (same results as vkr_bloom_blur with
+ * horizontal = 0 followed by vkr_postprocess; the intermediate bloom-2 image is never stored).
+ * `bloom1` is the pass-1 output, addressed like VkrBloomArgs.src. */
+typedef struct VkrBloomPostArgs {
+    const void *bloom1; const void *hdr; void *out_rgba8;
+    int32_t width, rows;
+    int32_t src_rows, src_row_offset;
+    int32_t wrap, clamp_lo, clamp_hi;
+    int32_t flags;
+} VkrBloomPostArgs;
+VKR_EXPORT int32_t vkr_bloomv_postprocess(const VkrBloomPostArgs *args, void *stream);
+
+/* IBL precompute.  Cube images are addressed by "face rows": row r of a 6*n-row image is row
+ * r % n of face r / n; [row_begin, row_end) selects the part this call computes, so the faces
+ * can be split over GPUs. */
+
+/* Replaces CreateSkyboxCubemap's six draws (VulkanRenderer.cs:653-732). */
+VKR_EXPORT int32_t vkr_ibl_equirect_to_cube(const void *src, int32_t src_w, int32_t src_h, int32_t src_format,
+                                 void *cube, int32_t n, int32_t row_begin, int32_t row_end, void *stream);
+/* Replaces CreateIrradianceCubemap's six draws (VulkanRenderer.cs:734-813). */
+VKR_EXPORT int32_t vkr_ibl_irradiance(const void *env, int32_t env_n, void *out, int32_t n, int32_t order,
+                           int32_t row_begin, int32_t row_end, void *stream);
+/* Replaces the six draws of one mip of CreatePrefilteredCubemap (VulkanRenderer.cs:855-884). */
+VKR_EXPORT int32_t vkr_ibl_prefilter(const void *env, int32_t env_n, void *out, int32_t n, float roughness,
+                          int32_t row_begin, int32_t row_end, void *stream);
+/* Replaces CreateBRDFLUTTexture's draw (VulkanRenderer.cs:966-989); rows of the n^2 RG16F image. */
+VKR_EXPORT int32_t vkr_ibl_brdf_lut(void *out, int32_t n, int32_t row_begin, int32_t row_end, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Layer 2: renderer object (host pointers in, device images owned by the context)
+ * ------------------------------------------------------------------------------------------ */
+
+typedef struct vkr_ctx vkr_ctx;
+
+/* The reference's compile-time constants (VulkanRenderer.cs:60-76,1274,1300,1323,1348) as
+ * run-time parameters.  Zero in any size field selects the reference's value. */
+typedef struct VkrConfig {
+    int32_t device;            /* HIP device ordinal */
+    int32_t width, height;     /* frame size            (reference: 1920 x 1080, Program.cs:48) */
+    int32_t max_lights;        /* MaxLights             (32) */
+    int32_t dir_shadow_res;    /* ShadowMapResolution   (1024) */
+    int32_t point_shadow_res;  /* PointShadowMapResolution (256) */
+    int32_t env_res;           /* environment cube face (512) */
+    int32_t irradiance_res;    /* (32) */
+    int32_t prefilter_res;     /* (128) */
+    int32_t prefilter_mips;    /* (5) */
+    int32_t brdf_lut_res;      /* (512) */
+    int32_t frames_in_flight;  /* MaxFramesInFlight     (2) */
+    int32_t flags;             /* VKR_POST_* */
+} VkrConfig;
+
+#define VKR_TARGET_COLOR 0      /* composition colour, RGBA16F WxH */
+#define VKR_TARGET_THRESHOLD 1  /* thresholded colour, RGBA16F WxH */
+#define VKR_TARGET_BLOOM1 2     /* RGBA16F WxH */
+#define VKR_TARGET_BLOOM2 3     /* RGBA16F WxH */
+#define VKR_TARGET_LDR 4        /* RGBA8 WxH */
+#define VKR_TARGET_ENV 5        /* RGBA16F cube */
+#define VKR_TARGET_IRRADIANCE 6 /* RGBA16F cube */
+#define VKR_TARGET_PREFILTER 7  /* RGBA16F cube, mip selected by `mip` */
+#define VKR_TARGET_BRDF_LUT 8   /* RG16F */
+
+VKR_EXPORT int32_t vkr_create(const VkrConfig *config, vkr_ctx **out);        /* VulkanRenderer..ctor, VulkanRenderer.cs:177 */
+VKR_EXPORT int32_t vkr_destroy(vkr_ctx *ctx);                                 /* Dispose */
+VKR_EXPORT int32_t vkr_resize(vkr_ctx *ctx, int32_t width, int32_t height);   /* RecreateSwapchain, VulkanRenderer.cs:1087-1127 */
+
+VKR_EXPORT int32_t vkr_update_scene_info(vkr_ctx *ctx, const VkrSceneInfo *info);               /* UpdateSceneInfo, :635-646 */
+VKR_EXPORT int32_t vkr_set_lights(vkr_ctx *ctx, const VkrLightInfo *lights, int32_t n, int32_t coverage_mode); /* Lights, :65 */
+VKR_EXPORT int32_t vkr_begin_frame(vkr_ctx *ctx);                                                /* BeginFrame, :286-318 */
+/* EndFrame, :320-623: composition pass, bloom 1, bloom 2, post-process, then advances the frame index. */
+VKR_EXPORT int32_t vkr_end_frame(vkr_ctx *ctx);
+VKR_EXPORT int32_t vkr_current_frame(vkr_ctx *ctx);
+
+/* Inputs the out-of-scope geometry / shadow passes would have produced for the current frame. */
+VKR_EXPORT int32_t vkr_upload_gbuffer(vkr_ctx *ctx, const void *albedo, const void *normal, const void *arm, const void *position);
+VKR_EXPORT int32_t vkr_upload_background(vkr_ctx *ctx, const void *rgba16f_or_null);
+VKR_EXPORT int32_t vkr_upload_dir_shadow(vkr_ctx *ctx, const float *depth);
+VKR_EXPORT int32_t vkr_upload_point_shadow(vkr_ctx *ctx, int32_t light, const float *depth_cube);
+
+/* IBL precompute (synchronous, like the reference's QueueWaitIdle after each). */
+VKR_EXPORT int32_t vkr_create_skybox_cubemap(vkr_ctx *ctx, const void *equirect, int32_t w, int32_t h, int32_t src_format); /* :653 */
+VKR_EXPORT int32_t vkr_upload_env_cube(vkr_ctx *ctx, const void *rgba16f_cube);  /* an environment cube given directly */
+VKR_EXPORT int32_t vkr_create_irradiance_cubemap(vkr_ctx *ctx, int32_t order);   /* :734 */
+VKR_EXPORT int32_t vkr_create_prefiltered_cubemap(vkr_ctx *ctx);                 /* :815 */
+VKR_EXPORT int32_t vkr_create_brdf_lut(vkr_ctx *ctx);                            /* :966 */
+
+/* Individual passes of EndFrame, for callers that mirror RenderStage's begin/draw/end shape. */
+VKR_EXPORT int32_t vkr_pass_composition(vkr_ctx *ctx);
+VKR_EXPORT int32_t vkr_pass_bloom(vkr_ctx *ctx, int32_t horizontal);
+VKR_EXPORT int32_t vkr_pass_postprocess(vkr_ctx *ctx);
+
+/* Copies a target of frame `frame` (or an IBL image) to host memory; waits for pending work. */
+VKR_EXPORT int32_t vkr_read(vkr_ctx *ctx, int32_t frame, int32_t target, int32_t mip, void *host, int64_t host_bytes);
+VKR_EXPORT int32_t vkr_sync(vkr_ctx *ctx); /* WaitIdle */
+
+/* Milliseconds the passes of the most recent EndFrame took on the device (HIP events). */
+typedef struct VkrTiming {
+    float shade_ms, bloom_h_ms, bloom_v_post_ms, frame_ms;
+} VkrTiming;
+VKR_EXPORT int32_t vkr_get_timing(vkr_ctx *ctx, VkrTiming *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VKR_HIP_H */

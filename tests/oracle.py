@@ -1,0 +1,197 @@
+"""ctypes wrapper of the CPU oracle (oracle/libvkr_oracle.so).  Test infrastructure: imported only by
+tests, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by the package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "libvkr_oracle.so")
+
+WRAP_REPEAT, WRAP_CLAMP = 0, 1
+SRC_RGBA8_SRGB, SRC_RGBA16F = 0, 1
+
+_lib = None
+
+
+class ShadeArgs(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32),
+                ("albedo", C.c_void_p), ("normal", C.c_void_p), ("arm", C.c_void_p), ("position", C.c_void_p),
+                ("background", C.c_void_p), ("scene", C.c_void_p),
+                ("lights", C.c_void_p), ("n_lights", C.c_int32),
+                ("dir_shadow", C.c_void_p), ("dir_res", C.c_int32),
+                ("cube_shadow", C.c_void_p), ("cube_res", C.c_int32),
+                ("irradiance", C.c_void_p), ("irr_res", C.c_int32),
+                ("prefilter", C.c_void_p), ("pref_res", C.c_int32),
+                ("brdf_lut", C.c_void_p), ("lut_res", C.c_int32),
+                ("out_color", C.c_void_p), ("out_threshold", C.c_void_p)]
+
+
+def build() -> None:
+    subprocess.run(["make", "-C", ORACLE_DIR, "-s"], check=True)
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = C.CDLL(LIB_PATH)
+        _lib.orc_aces.restype = C.c_float
+        _lib.orc_aces.argtypes = [C.c_float]
+        _lib.orc_radical_inverse.restype = C.c_float
+        _lib.orc_radical_inverse.argtypes = [C.c_uint32]
+        _lib.orc_normal_distribution.restype = C.c_float
+        _lib.orc_normal_distribution.argtypes = [C.c_float, C.c_float]
+        _lib.orc_geometry_schlick.restype = C.c_float
+        _lib.orc_geometry_schlick.argtypes = [C.c_float, C.c_float]
+        _lib.orc_texcube_depth_nearest.restype = C.c_float
+        _lib.orc_prefilter.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float]
+    return _lib
+
+
+def _p(a: np.ndarray | None) -> C.c_void_p:
+    if a is None:
+        return C.c_void_p(0)
+    assert a.flags["C_CONTIGUOUS"]
+    return C.c_void_p(a.ctypes.data)
+
+
+def omp_threads() -> int:
+    return load().orc_omp_threads()
+
+
+def f32_to_f16(a: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    out = np.empty(a.shape, dtype=np.uint16)
+    load().orc_f32_to_f16(_p(a), _p(out), C.c_int64(a.size))
+    return out
+
+
+def f16_to_f32(a: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint16)
+    out = np.empty(a.shape, dtype=np.float32)
+    load().orc_f16_to_f32(_p(a), _p(out), C.c_int64(a.size))
+    return out
+
+
+def shade(f, background: np.ndarray | None = None, rows: tuple[int, int] | None = None):
+    """Composition pass on a synth.FrameInputs; returns (color, threshold) uint16 [H, W, 4]."""
+    lib = load()
+    color = np.zeros((f.height, f.width, 4), dtype=np.uint16)
+    thr = np.zeros((f.height, f.width, 4), dtype=np.uint16)
+    scene = np.ascontiguousarray(f.scene).reshape(1)
+    lights = np.ascontiguousarray(f.lights)
+    a = ShadeArgs()
+    a.width, a.height = f.width, f.height
+    a.albedo, a.normal, a.arm, a.position = _p(f.albedo), _p(f.normal), _p(f.arm), _p(f.position)
+    a.background = _p(background)
+    a.scene = _p(scene)
+    a.lights, a.n_lights = (_p(lights) if len(lights) else C.c_void_p(0)), len(lights)
+    a.dir_shadow, a.dir_res = _p(f.dir_shadow), f.dir_shadow.shape[-1]
+    a.cube_shadow, a.cube_res = _p(f.cube_shadow), f.cube_shadow.shape[-1]
+    a.irradiance, a.irr_res = _p(f.irradiance), f.irradiance.shape[1]
+    a.prefilter, a.pref_res = _p(f.prefilter), f.prefilter.shape[1]
+    a.brdf_lut, a.lut_res = _p(f.brdf_lut), f.brdf_lut.shape[0]
+    a.out_color, a.out_threshold = _p(color), _p(thr)
+    r0, r1 = (0, f.height) if rows is None else rows
+    lib.orc_shade(C.byref(a), r0, r1)
+    return color, thr
+
+
+def bloom_blur(src: np.ndarray, horizontal: bool, wrap: int, true_bilinear: bool = False) -> np.ndarray:
+    src = np.ascontiguousarray(src, dtype=np.uint16)
+    h, w = src.shape[:2]
+    dst = np.empty_like(src)
+    load().orc_bloom_blur(_p(src), _p(dst), w, h, int(horizontal), wrap, int(true_bilinear))
+    return dst
+
+
+def postprocess(hdr: np.ndarray, bloom: np.ndarray, srgb_target: bool = False) -> np.ndarray:
+    hdr = np.ascontiguousarray(hdr, dtype=np.uint16)
+    bloom = np.ascontiguousarray(bloom, dtype=np.uint16)
+    h, w = hdr.shape[:2]
+    out = np.empty((h, w, 4), dtype=np.uint8)
+    load().orc_postprocess(_p(hdr), _p(bloom), _p(out), w, h, int(srgb_target))
+    return out
+
+
+def frame_chain(f, background=None):
+    """The whole per-frame chain (VulkanRenderer.cs:430-557): returns dict of every target."""
+    color, thr = shade(f, background)
+    b1 = bloom_blur(thr, True, WRAP_REPEAT)
+    b2 = bloom_blur(b1, False, WRAP_CLAMP)
+    ldr = postprocess(color, b2)
+    return {"color": color, "threshold": thr, "bloom1": b1, "bloom2": b2, "ldr": ldr}
+
+
+def equirect_to_cube(src: np.ndarray, n: int) -> np.ndarray:
+    src = np.ascontiguousarray(src)
+    fmt = SRC_RGBA8_SRGB if src.dtype == np.uint8 else SRC_RGBA16F
+    cube = np.empty((6, n, n, 4), dtype=np.uint16)
+    load().orc_equirect_to_cube(_p(src), src.shape[1], src.shape[0], fmt, _p(cube), n)
+    return cube
+
+
+def irradiance(env: np.ndarray, n: int, order: int = 0) -> np.ndarray:
+    env = np.ascontiguousarray(env, dtype=np.uint16)
+    out = np.empty((6, n, n, 4), dtype=np.uint16)
+    load().orc_irradiance(_p(env), env.shape[1], _p(out), n, order)
+    return out
+
+
+def prefilter(env: np.ndarray, n: int, roughness: float) -> np.ndarray:
+    env = np.ascontiguousarray(env, dtype=np.uint16)
+    out = np.empty((6, n, n, 4), dtype=np.uint16)
+    load().orc_prefilter(_p(env), env.shape[1], _p(out), n, C.c_float(roughness))
+    return out
+
+
+def brdf_lut(n: int) -> np.ndarray:
+    out = np.empty((n, n, 2), dtype=np.uint16)
+    load().orc_brdf_lut(_p(out), n)
+    return out
+
+
+def face_dir(f: int, i: int, j: int, n: int) -> np.ndarray:
+    out = np.empty(3, dtype=np.float32)
+    load().orc_face_dir(f, i, j, n, _p(out))
+    return out
+
+
+def cube_fold(n: int, f: int, i: int, j: int):
+    out = np.empty(3, dtype=np.int32)
+    ok = load().orc_cube_fold(n, f, i, j, _p(out))
+    return (int(ok), tuple(int(v) for v in out))
+
+
+def texcube_rgb_linear(cube: np.ndarray, d) -> np.ndarray:
+    cube = np.ascontiguousarray(cube, dtype=np.uint16)
+    d = np.ascontiguousarray(d, dtype=np.float32)
+    out = np.empty(3, dtype=np.float32)
+    load().orc_texcube_rgb_linear(_p(cube), cube.shape[1], _p(d), _p(out))
+    return out
+
+
+def texcube_depth_nearest(cube: np.ndarray, d) -> float:
+    cube = np.ascontiguousarray(cube, dtype=np.float32)
+    d = np.ascontiguousarray(d, dtype=np.float32)
+    return float(load().orc_texcube_depth_nearest(_p(cube), cube.shape[1], _p(d)))
+
+
+def tex2d_rg_linear_repeat(img: np.ndarray, s: float, t: float) -> np.ndarray:
+    img = np.ascontiguousarray(img, dtype=np.uint16)
+    out = np.empty(2, dtype=np.float32)
+    load().orc_tex2d_rg_linear_repeat(_p(img), img.shape[1], img.shape[0], C.c_float(s), C.c_float(t), _p(out))
+    return out
+
+
+def equirect_uv(d) -> np.ndarray:
+    d = np.ascontiguousarray(d, dtype=np.float32)
+    out = np.empty(2, dtype=np.float32)
+    load().orc_equirect_uv(_p(d), _p(out))
+    return out

@@ -1,0 +1,148 @@
+"""ctypes binding of libvkr_hip.so (include/vkr_hip.h).
+
+The library is the product: there is no CPU fallback.  Loading fails loudly when the shared object
+is missing (run `python -c "import __graft_entry__ as g; g.build()"` or `make -C vulkanrenderer_amd/csrc`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvkr_hip.so")
+
+VKR_OK = 0
+VKR_ERR_INVALID, VKR_ERR_HIP, VKR_ERR_UNSUPPORTED, VKR_ERR_ORDER, VKR_ERR_NO_DEVICE = -1, -2, -3, -4, -5
+COVERAGE_FULLSCREEN = 0
+WRAP_REPEAT, WRAP_CLAMP = 0, 1
+SRC_RGBA8_SRGB, SRC_RGBA16F = 0, 1
+POST_SRGB_TARGET = 1
+IRRADIANCE_SEQUENTIAL, IRRADIANCE_PHI_SLICES = 0, 1
+(TARGET_COLOR, TARGET_THRESHOLD, TARGET_BLOOM1, TARGET_BLOOM2, TARGET_LDR,
+ TARGET_ENV, TARGET_IRRADIANCE, TARGET_PREFILTER, TARGET_BRDF_LUT) = range(9)
+
+
+class VkrError(RuntimeError):
+    """A libvkr_hip call returned a negative status (the reference throws `Exception` on any non-Success VkResult)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libvkr_hip error {code}: {message}")
+        self.code = code
+
+
+class SceneInfo(C.Structure):
+    """VulkanRenderer.cs:11-20 (240 bytes)."""
+    _fields_ = [("camera_view", C.c_float * 16), ("camera_projection", C.c_float * 16),
+                ("camera_position", C.c_float * 3), ("_pad0", C.c_float),
+                ("dir_light_direction", C.c_float * 3), ("_pad1", C.c_float),
+                ("dir_light_color", C.c_float * 3), ("_pad2", C.c_float),
+                ("light_space_matrix", C.c_float * 16)]
+
+
+class LightInfo(C.Structure):
+    """VulkanRenderer.cs:22-28 (92 bytes)."""
+    _fields_ = [("model", C.c_float * 16), ("position", C.c_float * 3), ("_pad0", C.c_float), ("color", C.c_float * 3)]
+
+
+class ShadeArgs(C.Structure):
+    _fields_ = [("width", C.c_int32), ("rows", C.c_int32),
+                ("albedo", C.c_void_p), ("normal", C.c_void_p), ("arm", C.c_void_p), ("position", C.c_void_p),
+                ("background", C.c_void_p),
+                ("scene", SceneInfo),
+                ("lights", C.c_void_p), ("n_lights", C.c_int32), ("coverage_mode", C.c_int32),
+                ("dir_shadow", C.c_void_p), ("dir_res", C.c_int32),
+                ("cube_shadow", C.c_void_p), ("cube_res", C.c_int32),
+                ("irradiance", C.c_void_p), ("irr_res", C.c_int32),
+                ("prefilter", C.c_void_p), ("pref_res", C.c_int32),
+                ("brdf_lut", C.c_void_p), ("lut_res", C.c_int32),
+                ("out_color", C.c_void_p), ("out_threshold", C.c_void_p)]
+
+
+class BloomArgs(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("width", C.c_int32), ("rows", C.c_int32),
+                ("src_rows", C.c_int32), ("src_row_offset", C.c_int32), ("horizontal", C.c_int32),
+                ("wrap", C.c_int32), ("clamp_lo", C.c_int32), ("clamp_hi", C.c_int32)]
+
+
+class BloomPostArgs(C.Structure):
+    _fields_ = [("bloom1", C.c_void_p), ("hdr", C.c_void_p), ("out_rgba8", C.c_void_p),
+                ("width", C.c_int32), ("rows", C.c_int32), ("src_rows", C.c_int32), ("src_row_offset", C.c_int32),
+                ("wrap", C.c_int32), ("clamp_lo", C.c_int32), ("clamp_hi", C.c_int32), ("flags", C.c_int32)]
+
+
+class Config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "device", "width", "height", "max_lights", "dir_shadow_res", "point_shadow_res", "env_res",
+        "irradiance_res", "prefilter_res", "prefilter_mips", "brdf_lut_res", "frames_in_flight", "flags")]
+
+
+class Timing(C.Structure):
+    _fields_ = [("shade_ms", C.c_float), ("bloom_h_ms", C.c_float), ("bloom_v_post_ms", C.c_float), ("frame_ms", C.c_float)]
+
+
+assert C.sizeof(SceneInfo) == 240 and C.sizeof(LightInfo) == 92
+
+_i32, _vp, _f = C.c_int32, C.c_void_p, C.c_float
+# name -> argument types; every function returns int32 except vkr_last_error
+PROTOTYPES = {
+    "vkr_abi_version": [],
+    "vkr_device_count": [],
+    "vkr_shade": [C.POINTER(ShadeArgs), _vp],
+    "vkr_bloom_blur": [C.POINTER(BloomArgs), _vp],
+    "vkr_postprocess": [_vp, _vp, _vp, _i32, _i32, _i32, _vp],
+    "vkr_bloomv_postprocess": [C.POINTER(BloomPostArgs), _vp],
+    "vkr_ibl_equirect_to_cube": [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp],
+    "vkr_ibl_irradiance": [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp],
+    "vkr_ibl_prefilter": [_vp, _i32, _vp, _i32, _f, _i32, _i32, _vp],
+    "vkr_ibl_brdf_lut": [_vp, _i32, _i32, _i32, _vp],
+    "vkr_create": [C.POINTER(Config), C.POINTER(_vp)],
+    "vkr_destroy": [_vp],
+    "vkr_resize": [_vp, _i32, _i32],
+    "vkr_update_scene_info": [_vp, C.POINTER(SceneInfo)],
+    "vkr_set_lights": [_vp, _vp, _i32, _i32],
+    "vkr_begin_frame": [_vp],
+    "vkr_end_frame": [_vp],
+    "vkr_current_frame": [_vp],
+    "vkr_upload_gbuffer": [_vp, _vp, _vp, _vp, _vp],
+    "vkr_upload_background": [_vp, _vp],
+    "vkr_upload_dir_shadow": [_vp, _vp],
+    "vkr_upload_point_shadow": [_vp, _i32, _vp],
+    "vkr_create_skybox_cubemap": [_vp, _vp, _i32, _i32, _i32],
+    "vkr_upload_env_cube": [_vp, _vp],
+    "vkr_create_irradiance_cubemap": [_vp, _i32],
+    "vkr_create_prefiltered_cubemap": [_vp],
+    "vkr_create_brdf_lut": [_vp],
+    "vkr_pass_composition": [_vp],
+    "vkr_pass_bloom": [_vp, _i32],
+    "vkr_pass_postprocess": [_vp],
+    "vkr_read": [_vp, _i32, _i32, _i32, _vp, C.c_int64],
+    "vkr_sync": [_vp],
+    "vkr_get_timing": [_vp, C.POINTER(Timing)],
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Loads libvkr_hip.so once and sets the prototypes of every entry point in include/vkr_hip.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `make -C vulkanrenderer_amd/csrc` "
+                          "(there is no CPU fallback for the shading path)")
+    lib = C.CDLL(LIB_PATH)
+    lib.vkr_last_error.restype = C.c_char_p
+    lib.vkr_last_error.argtypes = []
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = C.c_int32
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(code: int) -> int:
+    if code < 0:
+        raise VkrError(code, load().vkr_last_error().decode("utf-8", "replace"))
+    return code

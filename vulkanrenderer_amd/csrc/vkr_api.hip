@@ -1,0 +1,493 @@
+// libvkr_hip.so: error reporting and the renderer object (layer 2 of include/vkr_hip.h).
+// The renderer object owns the device images the reference keeps per frame in flight
+// (G-buffer, shadow maps, composition / bloom / final targets: VulkanRenderer.cs:1129-1267)
+// and the IBL images, and runs the passes of EndFrame (VulkanRenderer.cs:430-557) on one stream.
+#include <stdarg.h>
+#include <string.h>
+#include <new>
+#include <vector>
+#include "vkr_host.h"
+
+namespace vkr {
+
+static thread_local char g_error[512] = "";
+
+int32_t fail(int32_t code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+struct Frame {
+    void *gbuf[4] = {nullptr, nullptr, nullptr, nullptr};  // albedo, normal, arm, position
+    void *background = nullptr;
+    bool has_background = false;
+    float *dir_shadow = nullptr;
+    float *cube_shadow = nullptr;
+    VkrLightInfo *lights = nullptr;
+    int n_lights = 0;
+    int coverage = VKR_COVERAGE_FULLSCREEN;
+    VkrSceneInfo scene;
+    void *color = nullptr, *threshold = nullptr, *bloom1 = nullptr, *bloom2 = nullptr, *ldr = nullptr;
+    bool bloom2_valid = false;
+};
+
+}  // namespace vkr
+
+struct vkr_ctx {
+    VkrConfig cfg;
+    hipStream_t stream = nullptr;
+    std::vector<vkr::Frame> frames;
+    int frame = 0;
+    bool in_frame = false;
+    void *env = nullptr, *irradiance = nullptr, *brdf_lut = nullptr;
+    std::vector<void *> prefilter;  // one image per mip
+    bool have_env = false, have_irr = false, have_pref = false, have_lut = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool timing_valid = false;
+};
+
+namespace vkr {
+
+static size_t rgba16f_bytes(int w, int h) { return (size_t)w * h * 8; }
+static size_t cube_bytes(int n) { return (size_t)6 * n * n * 8; }
+
+static void free_frame_sized(vkr_ctx *c)
+{
+    for (Frame &f : c->frames) {
+        for (void *&g : f.gbuf) { if (g) (void)hipFree(g); g = nullptr; }
+        void **imgs[] = {&f.background, &f.color, &f.threshold, &f.bloom1, &f.bloom2, &f.ldr};
+        for (void **p : imgs) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        f.has_background = false;
+        f.bloom2_valid = false;
+    }
+}
+
+static int32_t alloc_frame_sized(vkr_ctx *c)
+{
+    const size_t img = rgba16f_bytes(c->cfg.width, c->cfg.height);
+    for (Frame &f : c->frames) {
+        for (void *&g : f.gbuf) VKR_HIP_CHECK(hipMalloc(&g, img));
+        VKR_HIP_CHECK(hipMalloc(&f.background, img));
+        VKR_HIP_CHECK(hipMalloc(&f.color, img));
+        VKR_HIP_CHECK(hipMalloc(&f.threshold, img));
+        VKR_HIP_CHECK(hipMalloc(&f.bloom1, img));
+        VKR_HIP_CHECK(hipMalloc(&f.bloom2, img));
+        VKR_HIP_CHECK(hipMalloc(&f.ldr, (size_t)c->cfg.width * c->cfg.height * 4));
+    }
+    return VKR_OK;
+}
+
+static void destroy(vkr_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_frame_sized(c);
+    for (Frame &f : c->frames) {
+        if (f.dir_shadow) (void)hipFree(f.dir_shadow);
+        if (f.cube_shadow) (void)hipFree(f.cube_shadow);
+        if (f.lights) (void)hipFree(f.lights);
+    }
+    void *ibl[] = {c->env, c->irradiance, c->brdf_lut};
+    for (void *p : ibl) if (p) (void)hipFree(p);
+    for (void *p : c->prefilter) if (p) (void)hipFree(p);
+    for (hipEvent_t e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+#define VKR_CTX(c)                                                   \
+    VKR_REQUIRE((c) != nullptr, "%s: context is null", __func__);    \
+    VKR_HIP_CHECK(hipSetDevice((c)->cfg.device))
+
+static int32_t fill_shade_args(vkr_ctx *c, Frame &f, VkrShadeArgs &a)
+{
+    if (!(c->have_irr && c->have_pref && c->have_lut))
+        return fail(VKR_ERR_ORDER, "composition pass needs the irradiance cube, the prefiltered cube and the BRDF LUT; create them first");
+    memset(&a, 0, sizeof(a));
+    a.width = c->cfg.width; a.rows = c->cfg.height;
+    a.albedo = f.gbuf[0]; a.normal = f.gbuf[1]; a.arm = f.gbuf[2]; a.position = f.gbuf[3];
+    a.background = f.has_background ? f.background : nullptr;
+    a.scene = f.scene;
+    a.lights = f.lights; a.n_lights = f.n_lights; a.coverage_mode = f.coverage;
+    a.dir_shadow = f.dir_shadow; a.dir_res = c->cfg.dir_shadow_res;
+    a.cube_shadow = f.cube_shadow; a.cube_res = c->cfg.point_shadow_res;
+    a.irradiance = c->irradiance; a.irr_res = c->cfg.irradiance_res;
+    a.prefilter = c->prefilter[0]; a.pref_res = c->cfg.prefilter_res;
+    a.brdf_lut = c->brdf_lut; a.lut_res = c->cfg.brdf_lut_res;
+    a.out_color = f.color; a.out_threshold = f.threshold;
+    return VKR_OK;
+}
+
+static VkrBloomArgs bloom_args(vkr_ctx *c, Frame &f, int horizontal)
+{
+    VkrBloomArgs b;
+    memset(&b, 0, sizeof(b));
+    // pass 1 reads the thresholded target through textureSampler (REPEAT), pass 2 reads pass 1's
+    // output through bloomSampler (CLAMP_TO_EDGE): VulkanRenderer.cs:231-235
+    b.src = horizontal ? f.threshold : f.bloom1;
+    b.dst = horizontal ? f.bloom1 : f.bloom2;
+    b.width = c->cfg.width; b.rows = c->cfg.height; b.src_rows = c->cfg.height; b.src_row_offset = 0;
+    b.horizontal = horizontal;
+    b.wrap = horizontal ? VKR_WRAP_REPEAT : VKR_WRAP_CLAMP;
+    b.clamp_lo = 0; b.clamp_hi = c->cfg.height - 1;
+    return b;
+}
+
+}  // namespace vkr
+
+using namespace vkr;
+
+extern "C" const char *vkr_last_error(void) { return g_error; }
+extern "C" int32_t vkr_abi_version(void) { return 1; }
+
+extern "C" int32_t vkr_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int usable = 0;
+    for (int d = 0; d < n; d++) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) usable++;
+    }
+    return usable;
+}
+
+extern "C" int32_t vkr_create(const VkrConfig *config, vkr_ctx **out)
+{
+    VKR_REQUIRE(config && out, "vkr_create: null argument");
+    *out = nullptr;
+    VkrConfig cfg = *config;
+    // zero selects the reference's constants (VulkanRenderer.cs:60-76,1274,1300,1323,1348; Program.cs:48)
+    if (cfg.width == 0) cfg.width = 1920;
+    if (cfg.height == 0) cfg.height = 1080;
+    if (cfg.max_lights == 0) cfg.max_lights = 32;
+    if (cfg.dir_shadow_res == 0) cfg.dir_shadow_res = 1024;
+    if (cfg.point_shadow_res == 0) cfg.point_shadow_res = 256;
+    if (cfg.env_res == 0) cfg.env_res = 512;
+    if (cfg.irradiance_res == 0) cfg.irradiance_res = 32;
+    if (cfg.prefilter_res == 0) cfg.prefilter_res = 128;
+    if (cfg.prefilter_mips == 0) cfg.prefilter_mips = 5;
+    if (cfg.brdf_lut_res == 0) cfg.brdf_lut_res = 512;
+    if (cfg.frames_in_flight == 0) cfg.frames_in_flight = 2;
+    VKR_REQUIRE(cfg.width > 0 && cfg.height > 0, "vkr_create: bad frame size %dx%d", cfg.width, cfg.height);
+    VKR_REQUIRE(cfg.max_lights > 0 && cfg.frames_in_flight > 0 && cfg.frames_in_flight <= 8, "vkr_create: bad max_lights / frames_in_flight");
+    VKR_REQUIRE(cfg.dir_shadow_res > 0 && cfg.dir_shadow_res <= 32768 && cfg.point_shadow_res > 0 && cfg.point_shadow_res <= 8192, "vkr_create: bad shadow map size");
+    VKR_REQUIRE(cfg.env_res > 0 && cfg.irradiance_res > 0 && cfg.prefilter_res > 0 && cfg.brdf_lut_res > 0, "vkr_create: bad IBL size");
+    VKR_REQUIRE(cfg.prefilter_mips > 0 && (cfg.prefilter_res >> (cfg.prefilter_mips - 1)) > 0, "vkr_create: %d mips do not fit a %d^2 prefilter cube", cfg.prefilter_mips, cfg.prefilter_res);
+
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { (void)hipGetLastError(); return fail(VKR_ERR_NO_DEVICE, "vkr_create: no HIP device visible"); }
+    VKR_REQUIRE(cfg.device >= 0 && cfg.device < n, "vkr_create: device %d outside [0,%d)", cfg.device, n);
+    VKR_HIP_CHECK(hipSetDevice(cfg.device));
+
+    vkr_ctx *c = new (std::nothrow) vkr_ctx;
+    if (!c) return fail(VKR_ERR_INVALID, "vkr_create: out of host memory");
+    c->cfg = cfg;
+    c->frames.resize(cfg.frames_in_flight);
+    c->prefilter.assign(cfg.prefilter_mips, nullptr);
+    int32_t rc = VKR_OK;
+    auto body = [&]() -> int32_t {
+        VKR_HIP_CHECK(hipStreamCreate(&c->stream));
+        for (hipEvent_t &e : c->ev) VKR_HIP_CHECK(hipEventCreate(&e));
+        int32_t r = alloc_frame_sized(c);
+        if (r != VKR_OK) return r;
+        for (Frame &f : c->frames) {
+            memset(&f.scene, 0, sizeof(f.scene));
+            VKR_HIP_CHECK(hipMalloc((void **)&f.dir_shadow, (size_t)cfg.dir_shadow_res * cfg.dir_shadow_res * 4));
+            VKR_HIP_CHECK(hipMalloc((void **)&f.cube_shadow, (size_t)cfg.max_lights * 6 * cfg.point_shadow_res * cfg.point_shadow_res * 4));
+            VKR_HIP_CHECK(hipMalloc((void **)&f.lights, (size_t)cfg.max_lights * sizeof(VkrLightInfo)));
+        }
+        VKR_HIP_CHECK(hipMalloc(&c->env, cube_bytes(cfg.env_res)));
+        VKR_HIP_CHECK(hipMalloc(&c->irradiance, cube_bytes(cfg.irradiance_res)));
+        VKR_HIP_CHECK(hipMalloc(&c->brdf_lut, (size_t)cfg.brdf_lut_res * cfg.brdf_lut_res * 4));
+        for (int m = 0; m < cfg.prefilter_mips; m++) VKR_HIP_CHECK(hipMalloc(&c->prefilter[m], cube_bytes(cfg.prefilter_res >> m)));
+        return VKR_OK;
+    };
+    rc = body();
+    if (rc != VKR_OK) { destroy(c); return rc; }
+    *out = c;
+    return VKR_OK;
+}
+
+extern "C" int32_t vkr_destroy(vkr_ctx *ctx)
+{
+    destroy(ctx);
+    return VKR_OK;
+}
+
+extern "C" int32_t vkr_resize(vkr_ctx *c, int32_t width, int32_t height)
+{
+    VKR_CTX(c);
+    VKR_REQUIRE(width > 0 && height > 0, "vkr_resize: bad size %dx%d", width, height);
+    VKR_REQUIRE(!c->in_frame, "vkr_resize: called between BeginFrame and EndFrame");
+    VKR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    free_frame_sized(c);
+    c->cfg.width = width; c->cfg.height = height;
+    c->timing_valid = false;
+    return alloc_frame_sized(c);
+}
+
+extern "C" int32_t vkr_update_scene_info(vkr_ctx *c, const VkrSceneInfo *info)
+{
+    VKR_CTX(c);
+    VKR_REQUIRE(info != nullptr, "vkr_update_scene_info: info is null");
+    c->frames[c->frame].scene = *info;
+    return VKR_OK;
+}
+
+extern "C" int32_t vkr_set_lights(vkr_ctx *c, const VkrLightInfo *lights, int32_t n, int32_t coverage_mode)
+{
+    VKR_CTX(c);
+    VKR_REQUIRE(n >= 0 && n <= c->cfg.max_lights, "vkr_set_lights: %d lights outside [0,%d]", n, c->cfg.max_lights);
+    VKR_REQUIRE(n == 0 || lights != nullptr, "vkr_set_lights: lights is null");
+    if (coverage_mode != VKR_COVERAGE_FULLSCREEN) return fail(VKR_ERR_UNSUPPORTED, "vkr_set_lights: coverage mode %d is not implemented", coverage_mode);
+    Frame &f = c->frames[c->frame];
+    if (n) {
+        VKR_HIP_CHECK(hipMemcpyAsync(f.lights, lights, (size_t)n * sizeof(VkrLightInfo), hipMemcpyHostToDevice, c->stream));
+        VKR_HIP_CHECK(hipStreamSynchronize(c->stream));  // `lights` is borrowed for this call only
+    }
+    f.n_lights = n; f.coverage = coverage_mode;
+    return VKR_OK;
+}
+
+extern "C" int32_t vkr_begin_frame(vkr_ctx *c)
+{
+    VKR_CTX(c);
+    if (c->in_frame) return fail(VKR_ERR_ORDER, "Tried to begin frame before previous frame was finished!");  // VulkanRenderer.cs:288
+    c->in_frame = true;
+    return VKR_OK;
+}
+
+extern "C" int32_t vkr_current_frame(vkr_ctx *c)
+{
+    VKR_REQUIRE(c != nullptr, "vkr_current_frame: context is null");
+    return c->frame;
+}
+
+static int32_t upload(vkr_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    VKR_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    VKR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return VKR_OK;
+}
+
+extern "C" int32_t vkr_upload_gbuffer(vkr_ctx *c, const void *albedo, const void *normal, const void *arm, const void *position)
+{
+    VKR_CTX(c);
+    VKR_REQUIRE(albedo && normal && arm && position, "vkr_upload_gbuffer: an image is null");
+    Frame &f = c->frames[c->frame];
+    const void *src[4] = {albedo, normal, arm, position};
+    for (int i = 0; i < 4; i++) {
+        int32_t rc = upload(c, f.gbuf[i], src[i], rgba16f_bytes(c->cfg.width, c->cfg.height));
+        if (rc != VKR_OK) return rc;
+    }
+    return VKR_OK;
+}
+
+extern "C" int32_t vkr_upload_background(vkr_ctx *c, const void *img)
+{
+    VKR_CTX(c);
+    Frame &f = c->frames[c->frame];
+    f.has_background = img != nullptr;
+    if (!img) return VKR_OK;
+    return upload(c, f.background, img, rgba16f_bytes(c->cfg.width, c->cfg.height));
+}
+
+extern "C" int32_t vkr_upload_dir_shadow(vkr_ctx *c, const float *depth)
+{
+    VKR_CTX(c);
+    VKR_REQUIRE(depth != nullptr, "vkr_upload_dir_shadow: depth is null");
+    return upload(c, c->frames[c->frame].dir_shadow, depth, (size_t)c->cfg.dir_shadow_res * c->cfg.dir_shadow_res * 4);
+}
+
+extern "C" int32_t vkr_upload_point_shadow(vkr_ctx *c, int32_t light, const float *depth_cube)
+{
+    VKR_CTX(c);
+    VKR_REQUIRE(depth_cube != nullptr, "vkr_upload_point_shadow: depth cube is null");
+    VKR_REQUIRE(light >= 0 && light < c->cfg.max_lights, "vkr_upload_point_shadow: light %d outside [0,%d)", light, c->cfg.max_lights);
+    size_t per = (size_t)6 * c->cfg.point_shadow_res * c->cfg.point_shadow_res;
+    return upload(c, c->frames[c->frame].cube_shadow + per * light, depth_cube, per * 4);
+}
+
+extern "C" int32_t vkr_create_skybox_cubemap(vkr_ctx *c, const void *equirect, int32_t w, int32_t h, int32_t src_format)
+{
+    VKR_CTX(c);
+    VKR_REQUIRE(equirect != nullptr && w > 0 && h > 0, "vkr_create_skybox_cubemap: bad source image");
+    VKR_REQUIRE(src_format == VKR_SRC_RGBA8_SRGB || src_format == VKR_SRC_RGBA16F, "vkr_create_skybox_cubemap: unknown source format %d", src_format);
+    size_t bytes = (size_t)w * h * (src_format == VKR_SRC_RGBA8_SRGB ? 4 : 8);
+    void *src = nullptr;
+    VKR_HIP_CHECK(hipMalloc(&src, bytes));
+    int32_t rc = upload(c, src, equirect, bytes);
+    if (rc == VKR_OK) rc = vkr_ibl_equirect_to_cube(src, w, h, src_format, c->env, c->cfg.env_res, 0, 6 * c->cfg.env_res, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);  // the reference waits with QueueWaitIdle (VulkanRenderer.cs:714)
+    (void)hipFree(src);
+    if (rc != VKR_OK) return rc;
+    if (e != hipSuccess) return fail(VKR_ERR_HIP, "vkr_create_skybox_cubemap: %s", hipGetErrorString(e));
+    c->have_env = true;
+    return VKR_OK;
+}
+
+extern "C" int32_t vkr_upload_env_cube(vkr_ctx *c, const void *cube)
+{
+    VKR_CTX(c);
+    VKR_REQUIRE(cube != nullptr, "vkr_upload_env_cube: cube is null");
+    int32_t rc = upload(c, c->env, cube, cube_bytes(c->cfg.env_res));
+    if (rc == VKR_OK) c->have_env = true;
+    return rc;
+}
+
+extern "C" int32_t vkr_create_irradiance_cubemap(vkr_ctx *c, int32_t order)
+{
+    VKR_CTX(c);
+    if (!c->have_env) return fail(VKR_ERR_ORDER, "vkr_create_irradiance_cubemap: no environment cube yet");
+    int32_t rc = vkr_ibl_irradiance(c->env, c->cfg.env_res, c->irradiance, c->cfg.irradiance_res, order, 0, 6 * c->cfg.irradiance_res, c->stream);
+    if (rc != VKR_OK) return rc;
+    VKR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->have_irr = true;
+    return VKR_OK;
+}
+
+extern "C" int32_t vkr_create_prefiltered_cubemap(vkr_ctx *c)
+{
+    VKR_CTX(c);
+    if (!c->have_env) return fail(VKR_ERR_ORDER, "vkr_create_prefiltered_cubemap: no environment cube yet");
+    for (int m = 0; m < c->cfg.prefilter_mips; m++) {
+        // VulkanRenderer.cs:874: roughness = mip / (mips - 1)
+        float rough = c->cfg.prefilter_mips > 1 ? (float)m / (float)(c->cfg.prefilter_mips - 1) : 0.0f;
+        int n = c->cfg.prefilter_res >> m;
+        int32_t rc = vkr_ibl_prefilter(c->env, c->cfg.env_res, c->prefilter[m], n, rough, 0, 6 * n, c->stream);
+        if (rc != VKR_OK) return rc;
+    }
+    VKR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->have_pref = true;
+    return VKR_OK;
+}
+
+extern "C" int32_t vkr_create_brdf_lut(vkr_ctx *c)
+{
+    VKR_CTX(c);
+    int32_t rc = vkr_ibl_brdf_lut(c->brdf_lut, c->cfg.brdf_lut_res, 0, c->cfg.brdf_lut_res, c->stream);
+    if (rc != VKR_OK) return rc;
+    VKR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->have_lut = true;
+    return VKR_OK;
+}
+
+extern "C" int32_t vkr_pass_composition(vkr_ctx *c)
+{
+    VKR_CTX(c);
+    VkrShadeArgs a;
+    int32_t rc = fill_shade_args(c, c->frames[c->frame], a);
+    if (rc != VKR_OK) return rc;
+    return vkr_shade(&a, c->stream);
+}
+
+extern "C" int32_t vkr_pass_bloom(vkr_ctx *c, int32_t horizontal)
+{
+    VKR_CTX(c);
+    Frame &f = c->frames[c->frame];
+    VkrBloomArgs b = bloom_args(c, f, horizontal != 0);
+    int32_t rc = vkr_bloom_blur(&b, c->stream);
+    if (rc == VKR_OK && !horizontal) f.bloom2_valid = true;
+    return rc;
+}
+
+extern "C" int32_t vkr_pass_postprocess(vkr_ctx *c)
+{
+    VKR_CTX(c);
+    Frame &f = c->frames[c->frame];
+    if (!f.bloom2_valid) return fail(VKR_ERR_ORDER, "vkr_pass_postprocess: bloom pass 2 has not run for this frame");
+    return vkr_postprocess(f.color, f.bloom2, f.ldr, c->cfg.width, c->cfg.height, c->cfg.flags & VKR_POST_SRGB_TARGET, c->stream);
+}
+
+extern "C" int32_t vkr_end_frame(vkr_ctx *c)
+{
+    VKR_CTX(c);
+    if (!c->in_frame) return fail(VKR_ERR_ORDER, "Tried to end frame before beginning a new one!");  // VulkanRenderer.cs:322
+    Frame &f = c->frames[c->frame];
+    VkrShadeArgs a;
+    int32_t rc = fill_shade_args(c, f, a);
+    if (rc != VKR_OK) return rc;
+    VKR_HIP_CHECK(hipEventRecord(c->ev[0], c->stream));
+    if ((rc = vkr_shade(&a, c->stream)) != VKR_OK) return rc;
+    VKR_HIP_CHECK(hipEventRecord(c->ev[1], c->stream));
+    VkrBloomArgs b1 = bloom_args(c, f, 1);
+    if ((rc = vkr_bloom_blur(&b1, c->stream)) != VKR_OK) return rc;
+    VKR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
+    // bloom pass 2 and the post-process draw run as one kernel; bloom-2 is not stored
+    VkrBloomPostArgs bp;
+    memset(&bp, 0, sizeof(bp));
+    bp.bloom1 = f.bloom1; bp.hdr = f.color; bp.out_rgba8 = f.ldr;
+    bp.width = c->cfg.width; bp.rows = c->cfg.height; bp.src_rows = c->cfg.height; bp.src_row_offset = 0;
+    bp.wrap = VKR_WRAP_CLAMP; bp.clamp_lo = 0; bp.clamp_hi = c->cfg.height - 1;
+    bp.flags = c->cfg.flags & VKR_POST_SRGB_TARGET;
+    if ((rc = vkr_bloomv_postprocess(&bp, c->stream)) != VKR_OK) return rc;
+    VKR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
+    f.bloom2_valid = false;
+    c->timing_valid = true;
+    c->in_frame = false;
+    c->frame = (c->frame + 1) % c->cfg.frames_in_flight;  // VulkanRenderer.cs:622
+    return VKR_OK;
+}
+
+extern "C" int32_t vkr_read(vkr_ctx *c, int32_t frame, int32_t target, int32_t mip, void *host, int64_t host_bytes)
+{
+    VKR_CTX(c);
+    VKR_REQUIRE(host != nullptr, "vkr_read: host buffer is null");
+    const void *src = nullptr;
+    size_t bytes = 0;
+    const size_t img = rgba16f_bytes(c->cfg.width, c->cfg.height);
+    if (target <= VKR_TARGET_LDR) {
+        VKR_REQUIRE(frame >= 0 && frame < c->cfg.frames_in_flight, "vkr_read: frame %d outside [0,%d)", frame, c->cfg.frames_in_flight);
+        Frame &f = c->frames[frame];
+        switch (target) {
+        case VKR_TARGET_COLOR: src = f.color; bytes = img; break;
+        case VKR_TARGET_THRESHOLD: src = f.threshold; bytes = img; break;
+        case VKR_TARGET_BLOOM1: src = f.bloom1; bytes = img; break;
+        case VKR_TARGET_BLOOM2:
+            if (!f.bloom2_valid) return fail(VKR_ERR_ORDER, "vkr_read: bloom-2 is only stored by vkr_pass_bloom(ctx, 0)");
+            src = f.bloom2; bytes = img; break;
+        case VKR_TARGET_LDR: src = f.ldr; bytes = (size_t)c->cfg.width * c->cfg.height * 4; break;
+        default: return fail(VKR_ERR_INVALID, "vkr_read: unknown target %d", target);
+        }
+    } else {
+        switch (target) {
+        case VKR_TARGET_ENV: src = c->env; bytes = cube_bytes(c->cfg.env_res); break;
+        case VKR_TARGET_IRRADIANCE: src = c->irradiance; bytes = cube_bytes(c->cfg.irradiance_res); break;
+        case VKR_TARGET_PREFILTER:
+            VKR_REQUIRE(mip >= 0 && mip < c->cfg.prefilter_mips, "vkr_read: mip %d outside [0,%d)", mip, c->cfg.prefilter_mips);
+            src = c->prefilter[mip]; bytes = cube_bytes(c->cfg.prefilter_res >> mip); break;
+        case VKR_TARGET_BRDF_LUT: src = c->brdf_lut; bytes = (size_t)c->cfg.brdf_lut_res * c->cfg.brdf_lut_res * 4; break;
+        default: return fail(VKR_ERR_INVALID, "vkr_read: unknown target %d", target);
+        }
+    }
+    VKR_REQUIRE(host_bytes >= 0 && (size_t)host_bytes >= bytes, "vkr_read: host buffer holds %lld bytes, target needs %zu", (long long)host_bytes, bytes);
+    VKR_HIP_CHECK(hipMemcpyAsync(host, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    VKR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return VKR_OK;
+}
+
+extern "C" int32_t vkr_sync(vkr_ctx *c)
+{
+    VKR_CTX(c);
+    VKR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return VKR_OK;
+}
+
+extern "C" int32_t vkr_get_timing(vkr_ctx *c, VkrTiming *out)
+{
+    VKR_CTX(c);
+    VKR_REQUIRE(out != nullptr, "vkr_get_timing: out is null");
+    if (!c->timing_valid) return fail(VKR_ERR_ORDER, "vkr_get_timing: no frame has ended yet");
+    VKR_HIP_CHECK(hipEventSynchronize(c->ev[3]));
+    VKR_HIP_CHECK(hipEventElapsedTime(&out->shade_ms, c->ev[0], c->ev[1]));
+    VKR_HIP_CHECK(hipEventElapsedTime(&out->bloom_h_ms, c->ev[1], c->ev[2]));
+    VKR_HIP_CHECK(hipEventElapsedTime(&out->bloom_v_post_ms, c->ev[2], c->ev[3]));
+    VKR_HIP_CHECK(hipEventElapsedTime(&out->frame_ms, c->ev[0], c->ev[3]));
+    return VKR_OK;
+}

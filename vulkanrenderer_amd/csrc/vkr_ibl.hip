@@ -1,0 +1,296 @@
+// IBL precompute on gfx950: equirectangular -> cube, irradiance convolution, GGX prefilter and
+// the split-sum BRDF LUT (the four Create* functions of VulkanRenderer.cs:653-989).
+//
+// sin/cos of the fixed sample angles (Hammersley phi_i, the irradiance loop's phi/theta values)
+// and the sRGB decode table come from the host C library and are uploaded once per device, so
+// kernels never evaluate a transcendental function in the sample loops.
+#include <math.h>
+#include <mutex>
+#include "vkr_device.h"
+#include "vkr_host.h"
+
+namespace vkr {
+
+static constexpr float PI_F = 3.14159265359f;
+static constexpr int SAMPLE_COUNT = 1024;       // prefilter.frag:29, brdf.frag:93
+static constexpr int IRR_MAX_PHI = 256, IRR_MAX_THETA = 64;
+
+__device__ float2 g_hammersley_cs[SAMPLE_COUNT];  // (cos, sin) of phi_i = 2*PI * i/1024
+__device__ float2 g_irr_phi_cs[IRR_MAX_PHI];      // (cos, sin) of the irradiance loop's phi values
+__device__ float2 g_irr_theta_sc[IRR_MAX_THETA];  // (sin, cos) of its theta values
+__device__ float g_srgb_lut[256];                 // sRGB 8-bit -> linear
+
+static int g_irr_nphi = 0, g_irr_ntheta = 0;
+static std::mutex g_init_mutex;
+static bool g_device_ready[64];
+
+// Uploads the tables to the current device on first use.
+static int32_t ensure_tables()
+{
+    int dev = 0;
+    VKR_HIP_CHECK(hipGetDevice(&dev));
+    VKR_REQUIRE(dev >= 0 && dev < 64, "device ordinal %d out of range", dev);
+    std::lock_guard<std::mutex> lock(g_init_mutex);
+    if (g_device_ready[dev]) return VKR_OK;
+
+    static float2 ham[SAMPLE_COUNT], phi_cs[IRR_MAX_PHI], theta_sc[IRR_MAX_THETA];
+    static float srgb[256];
+    for (int i = 0; i < SAMPLE_COUNT; i++) {
+        float phi = (2.0f * PI_F) * ((float)i * (1.0f / 1024.0f));  // prefilter.frag:84
+        ham[i] = make_float2(cosf(phi), sinf(phi));
+    }
+    // irradiance.frag:21-26: the loop variables are binary32 running sums
+    int nphi = 0, ntheta = 0;
+    for (float phi = 0.0f; phi < 2.0f * PI_F; phi += 0.025f) {
+        VKR_REQUIRE(nphi < IRR_MAX_PHI, "irradiance phi table overflow");
+        phi_cs[nphi++] = make_float2(cosf(phi), sinf(phi));
+    }
+    for (float th = 0.0f; th < 0.5f * PI_F; th += 0.025f) {
+        VKR_REQUIRE(ntheta < IRR_MAX_THETA, "irradiance theta table overflow");
+        theta_sc[ntheta++] = make_float2(sinf(th), cosf(th));
+    }
+    g_irr_nphi = nphi; g_irr_ntheta = ntheta;
+    for (int i = 0; i < 256; i++) {
+        float c = (float)i * (1.0f / 255.0f);
+        srgb[i] = c <= 0.04045f ? c * (1.0f / 12.92f) : powf((c + 0.055f) * (1.0f / 1.055f), 2.4f);
+    }
+    VKR_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_hammersley_cs), ham, sizeof(ham)));
+    VKR_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_irr_phi_cs), phi_cs, sizeof(phi_cs)));
+    VKR_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_irr_theta_sc), theta_sc, sizeof(theta_sc)));
+    VKR_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_srgb_lut), srgb, sizeof(srgb)));
+    g_device_ready[dev] = true;
+    return VKR_OK;
+}
+
+// ---- equirectangular_to_cubemap.frag:8-24 ---------------------------------------------------
+
+VKR_DEV f3 fetch_src(const void *src, int fmt, int w, int x, int y)
+{
+    size_t t = (size_t)y * w + x;
+    if (fmt == VKR_SRC_RGBA8_SRGB) {
+        uint32_t v = ((const uint32_t *)src)[t];
+        return mk3(g_srgb_lut[v & 0xFF], g_srgb_lut[(v >> 8) & 0xFF], g_srgb_lut[(v >> 16) & 0xFF]);
+    }
+    rgba c = load_rgba16f(src, t);
+    return mk3(c.r, c.g, c.b);
+}
+
+__global__ __launch_bounds__(256) void equirect_kernel(const void *src, int sw, int sh, int fmt, uint2 *cube, int n, int row_begin, int row_end)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    int row = row_begin + blockIdx.y;
+    if (i >= n || row >= row_end) return;
+    int f = row / n, j = row - f * n;
+    f3 d = normalize3(face_dir(f, i, j, n));
+    float u = fma_(atan2f(d.z, d.x), 0.1591f, 0.5f);
+    float v = 1.0f - fma_(asinf(d.y), 0.3183f, 0.5f);
+    float x = u * (float)sw - 0.5f, y = v * (float)sh - 0.5f;
+    float fx = __builtin_floorf(x), fy = __builtin_floorf(y);
+    float al = x - fx, be = y - fy;
+    int i0 = wrap_repeat((int)fx, sw), i1 = wrap_repeat((int)fx + 1, sw);
+    int j0 = wrap_repeat((int)fy, sh), j1 = wrap_repeat((int)fy + 1, sh);
+    float w00 = (1.0f - al) * (1.0f - be), w10 = al * (1.0f - be), w01 = (1.0f - al) * be, w11 = al * be;
+    f3 a = fetch_src(src, fmt, sw, i0, j0), b = fetch_src(src, fmt, sw, i1, j0);
+    f3 c = fetch_src(src, fmt, sw, i0, j1), e = fetch_src(src, fmt, sw, i1, j1);
+    cube[(size_t)row * n + i] = pack4(fma_(w11, e.x, fma_(w01, c.x, fma_(w10, b.x, w00 * a.x))),
+                                      fma_(w11, e.y, fma_(w01, c.y, fma_(w10, b.y, w00 * a.y))),
+                                      fma_(w11, e.z, fma_(w01, c.z, fma_(w10, b.z, w00 * a.z))), 1.0f);
+}
+
+// ---- irradiance.frag:10-39 ------------------------------------------------------------------
+
+// One lane per output texel.  order 0: a single running sum (phi outer, theta inner), the
+// shader's own order.  order 1: every phi slice summed from zero, slice sums added in phi order.
+__global__ __launch_bounds__(64) void irradiance_kernel(const void *env, int env_n, uint2 *out, int n, int order, int nphi, int ntheta, int row_begin, int row_end)
+{
+    int i = blockIdx.x * 64 + threadIdx.x;
+    int row = row_begin + blockIdx.y;
+    if (i >= n || row >= row_end) return;
+    int f = row / n, j = row - f * n;
+    f3 N = normalize3(face_dir(f, i, j, n));
+    f3 right = normalize3(mk3(N.z, 0.0f, -N.x));  // normalize(cross((0,1,0), N))
+    f3 up = normalize3(cross3(N, right));
+    float ir = 0.0f, ig = 0.0f, ib = 0.0f;
+    for (int a = 0; a < nphi; a++) {
+        float2 pcs = g_irr_phi_cs[a];
+        float pr = 0.0f, pg = 0.0f, pb = 0.0f;
+        if (order == VKR_IRRADIANCE_SEQUENTIAL) { pr = ir; pg = ig; pb = ib; }
+        for (int b = 0; b < ntheta; b++) {
+            float2 tsc = g_irr_theta_sc[b];
+            float st = tsc.x, ct = tsc.y;
+            float tx = st * pcs.x, ty = st * pcs.y, tz = ct;
+            f3 sv = mk3(fma_(tz, N.x, fma_(ty, up.x, tx * right.x)),
+                        fma_(tz, N.y, fma_(ty, up.y, tx * right.y)),
+                        fma_(tz, N.z, fma_(ty, up.z, tx * right.z)));
+            f3 c = texcube_rgb_linear(env, env_n, sv);
+            pr = fma_(c.x * ct, st, pr);
+            pg = fma_(c.y * ct, st, pg);
+            pb = fma_(c.z * ct, st, pb);
+        }
+        if (order == VKR_IRRADIANCE_SEQUENTIAL) { ir = pr; ig = pg; ib = pb; }
+        else { ir += pr; ig += pg; ib += pb; }
+    }
+    float inv_count = rcp_rn((float)(nphi * ntheta));
+    out[(size_t)row * n + i] = pack4((PI_F * ir) * inv_count, (PI_F * ig) * inv_count, (PI_F * ib) * inv_count, 1.0f);
+}
+
+// ---- prefilter.frag / brdf.frag shared pieces -----------------------------------------------
+
+// prefilter.frag:65-73
+VKR_DEV float radical_inverse(uint32_t bits)
+{
+    return (float)__builtin_bitreverse32(bits) * 2.3283064365386963e-10f;
+}
+
+// (cos theta, sin theta) of GGX sample s at roughness r (prefilter.frag:82-86); lane-independent
+VKR_DEV float2 ggx_theta(int s, float rough)
+{
+    float a = rough * rough;
+    float xi_y = radical_inverse((uint32_t)s);
+    float cos_t = sqrt_rn((1.0f - xi_y) * rcp_rn(fma_(a * a - 1.0f, xi_y, 1.0f)));
+    float sin_t = sqrt_rn(fma_(-cos_t, cos_t, 1.0f));
+    return make_float2(cos_t, sin_t);
+}
+
+// prefilter.frag:21-63, one lane per output texel; the per-sample (cos theta, sin theta) pairs
+// depend only on the roughness and are built once per workgroup in LDS.
+__global__ __launch_bounds__(64) void prefilter_kernel(const void *env, int env_n, uint2 *out, int n, float rough, int row_begin, int row_end)
+{
+    __shared__ float2 theta_cs[SAMPLE_COUNT];
+    for (int s = threadIdx.x; s < SAMPLE_COUNT; s += 64) theta_cs[s] = ggx_theta(s, rough);
+    __syncthreads();
+    int i = blockIdx.x * 64 + threadIdx.x;
+    int row = row_begin + blockIdx.y;
+    if (i >= n || row >= row_end) return;
+    int f = row / n, j = row - f * n;
+    f3 N = normalize3(face_dir(f, i, j, n));
+    f3 tangent = __builtin_fabsf(N.z) < 0.999f ? normalize3(mk3(-N.y, N.x, 0.0f))   // cross((0,0,1), N)
+                                               : normalize3(mk3(0.0f, -N.z, N.y));  // cross((1,0,0), N)
+    f3 bitangent = cross3(N, tangent);
+    float cr = 0.0f, cg = 0.0f, cb = 0.0f, total = 0.0f;
+    for (int s = 0; s < SAMPLE_COUNT; s++) {
+        float2 pcs = g_hammersley_cs[s];
+        float2 tcs = theta_cs[s];
+        float hx = pcs.x * tcs.y, hy = pcs.y * tcs.y, hz = tcs.x;
+        f3 H = normalize3(mk3(fma_(N.x, hz, fma_(bitangent.x, hy, tangent.x * hx)),
+                              fma_(N.y, hz, fma_(bitangent.y, hy, tangent.y * hx)),
+                              fma_(N.z, hz, fma_(bitangent.z, hy, tangent.z * hx))));
+        float vh2 = 2.0f * dot3(N, H);  // V = N
+        f3 L = normalize3(mk3(fma_(vh2, H.x, -N.x), fma_(vh2, H.y, -N.y), fma_(vh2, H.z, -N.z)));
+        float NdotL = max0(dot3(N, L));
+        if (NdotL > 0.0f) {
+            f3 c = texcube_rgb_linear(env, env_n, L);  // the shader's mip level is clamped to 0 by the sampler
+            cr = fma_(c.x, NdotL, cr); cg = fma_(c.y, NdotL, cg); cb = fma_(c.z, NdotL, cb);
+            total += NdotL;
+        }
+    }
+    float iw = rcp_rn(total);
+    out[(size_t)row * n + i] = pack4(cr * iw, cg * iw, cb * iw, 1.0f);
+}
+
+// brdf.frag:81-119, one lane per texel; a workgroup works on one row (one roughness).
+__global__ __launch_bounds__(256) void brdf_lut_kernel(uint32_t *out, int n, int row_begin, int row_end)
+{
+    __shared__ float2 theta_cs[SAMPLE_COUNT];
+    int row = row_begin + blockIdx.y;
+    float rn = rcp_rn((float)n);
+    float rough = ((float)row + 0.5f) * rn;
+    for (int s = threadIdx.x; s < SAMPLE_COUNT; s += 256) theta_cs[s] = ggx_theta(s, rough);
+    __syncthreads();
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || row >= row_end) return;
+    float NdotV = ((float)i + 0.5f) * rn;
+    float Vx = sqrt_rn(fma_(-NdotV, NdotV, 1.0f)), Vz = NdotV;
+    float k = (rough * rough) * 0.5f;
+    float gV = max0(Vz) * rcp_rn(fma_(max0(Vz), 1.0f - k, k));  // GeometrySchlickGGX(NdotV), brdf.frag:60-69
+    float A = 0.0f, B = 0.0f;
+    for (int s = 0; s < SAMPLE_COUNT; s++) {
+        float2 pcs = g_hammersley_cs[s];
+        float2 tcs = theta_cs[s];
+        float hx = pcs.x * tcs.y, hy = pcs.y * tcs.y, hz = tcs.x;
+        // with N = (0,0,1): tangent = (0,-1,0), bitangent = (1,0,-0) (brdf.frag:52-56), so
+        // sampleVec = (hy, -hx, hz); the fma chain below is that product written out.
+        f3 H = normalize3(mk3(fma_(0.0f, hz, fma_(1.0f, hy, 0.0f * hx)),
+                              fma_(0.0f, hz, fma_(0.0f, hy, -1.0f * hx)),
+                              fma_(1.0f, hz, fma_(-0.0f, hy, 0.0f * hx))));
+        float vh = fma_(Vz, H.z, fma_(0.0f, H.y, Vx * H.x));
+        float vh2 = 2.0f * vh;
+        f3 L = normalize3(mk3(fma_(vh2, H.x, -Vx), fma_(vh2, H.y, -0.0f), fma_(vh2, H.z, -Vz)));
+        float NdotL = max0(L.z), NdotH = max0(H.z), VdotH = max0(vh);
+        if (NdotL > 0.0f) {
+            float G = (NdotL * rcp_rn(fma_(NdotL, 1.0f - k, k))) * gV;
+            float G_vis = (G * VdotH) * rcp_rn(NdotH * NdotV);
+            float Fc = pow5(1.0f - VdotH);
+            A = fma_(1.0f - Fc, G_vis, A);
+            B = fma_(Fc, G_vis, B);
+        }
+    }
+    half2_t o; o.x = to_f16(A * (1.0f / 1024.0f)); o.y = to_f16(B * (1.0f / 1024.0f));
+    out[(size_t)row * n + i] = __builtin_bit_cast(uint32_t, o);
+}
+
+static int32_t check_rows(const char *who, int n, int total_rows, int row_begin, int row_end)
+{
+    VKR_REQUIRE(n > 0, "%s: bad size %d", who, n);
+    VKR_REQUIRE(row_begin >= 0 && row_begin <= row_end && row_end <= total_rows, "%s: rows [%d,%d) outside [0,%d)", who, row_begin, row_end, total_rows);
+    return VKR_OK;
+}
+
+}  // namespace vkr
+
+extern "C" int32_t vkr_ibl_equirect_to_cube(const void *src, int32_t src_w, int32_t src_h, int32_t src_format, void *cube, int32_t n,
+                                            int32_t row_begin, int32_t row_end, void *stream)
+{
+    using namespace vkr;
+    VKR_REQUIRE(src && cube, "vkr_ibl_equirect_to_cube: an image is null");
+    VKR_REQUIRE(src_w > 0 && src_h > 0, "vkr_ibl_equirect_to_cube: bad source size %dx%d", src_w, src_h);
+    VKR_REQUIRE(src_format == VKR_SRC_RGBA8_SRGB || src_format == VKR_SRC_RGBA16F, "vkr_ibl_equirect_to_cube: unknown source format %d", src_format);
+    int32_t rc = check_rows("vkr_ibl_equirect_to_cube", n, 6 * n, row_begin, row_end);
+    if (rc != VKR_OK) return rc;
+    if ((rc = ensure_tables()) != VKR_OK) return rc;
+    if (row_end == row_begin) return VKR_OK;
+    dim3 grid((n + 255) / 256, row_end - row_begin);
+    hipLaunchKernelGGL(equirect_kernel, grid, dim3(256), 0, as_stream(stream), src, src_w, src_h, src_format, (uint2 *)cube, n, row_begin, row_end);
+    return launch_status("vkr_ibl_equirect_to_cube");
+}
+
+extern "C" int32_t vkr_ibl_irradiance(const void *env, int32_t env_n, void *out, int32_t n, int32_t order, int32_t row_begin, int32_t row_end, void *stream)
+{
+    using namespace vkr;
+    VKR_REQUIRE(env && out && env_n > 0, "vkr_ibl_irradiance: an image is null or env size is bad");
+    VKR_REQUIRE(order == VKR_IRRADIANCE_SEQUENTIAL || order == VKR_IRRADIANCE_PHI_SLICES, "vkr_ibl_irradiance: unknown summation order %d", order);
+    int32_t rc = check_rows("vkr_ibl_irradiance", n, 6 * n, row_begin, row_end);
+    if (rc != VKR_OK) return rc;
+    if ((rc = ensure_tables()) != VKR_OK) return rc;
+    if (row_end == row_begin) return VKR_OK;
+    dim3 grid((n + 63) / 64, row_end - row_begin);
+    hipLaunchKernelGGL(irradiance_kernel, grid, dim3(64), 0, as_stream(stream), env, env_n, (uint2 *)out, n, order, g_irr_nphi, g_irr_ntheta, row_begin, row_end);
+    return launch_status("vkr_ibl_irradiance");
+}
+
+extern "C" int32_t vkr_ibl_prefilter(const void *env, int32_t env_n, void *out, int32_t n, float roughness, int32_t row_begin, int32_t row_end, void *stream)
+{
+    using namespace vkr;
+    VKR_REQUIRE(env && out && env_n > 0, "vkr_ibl_prefilter: an image is null or env size is bad");
+    VKR_REQUIRE(roughness >= 0.0f && roughness <= 1.0f, "vkr_ibl_prefilter: roughness %g outside [0,1]", (double)roughness);
+    int32_t rc = check_rows("vkr_ibl_prefilter", n, 6 * n, row_begin, row_end);
+    if (rc != VKR_OK) return rc;
+    if ((rc = ensure_tables()) != VKR_OK) return rc;
+    if (row_end == row_begin) return VKR_OK;
+    dim3 grid((n + 63) / 64, row_end - row_begin);
+    hipLaunchKernelGGL(prefilter_kernel, grid, dim3(64), 0, as_stream(stream), env, env_n, (uint2 *)out, n, roughness, row_begin, row_end);
+    return launch_status("vkr_ibl_prefilter");
+}
+
+extern "C" int32_t vkr_ibl_brdf_lut(void *out, int32_t n, int32_t row_begin, int32_t row_end, void *stream)
+{
+    using namespace vkr;
+    VKR_REQUIRE(out != nullptr, "vkr_ibl_brdf_lut: output image is null");
+    int32_t rc = check_rows("vkr_ibl_brdf_lut", n, n, row_begin, row_end);
+    if (rc != VKR_OK) return rc;
+    if ((rc = ensure_tables()) != VKR_OK) return rc;
+    if (row_end == row_begin) return VKR_OK;
+    dim3 grid((n + 255) / 256, row_end - row_begin);
+    hipLaunchKernelGGL(brdf_lut_kernel, grid, dim3(256), 0, as_stream(stream), (uint32_t *)out, n, row_begin, row_end);
+    return launch_status("vkr_ibl_brdf_lut");
+}

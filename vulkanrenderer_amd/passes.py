@@ -1,0 +1,162 @@
+"""Layer-1 passes of libvkr_hip.so on torch-owned device memory.
+
+torch is used for what it is good at here -- allocating HBM, streams, and `torch.distributed` --
+while every pass is one C-ABI call into the hand-written kernels, launched on torch's current
+stream.  RGBA16F images are float16 tensors [rows, width, 4]; depth maps float32; the final image
+uint8 [rows, width, 4]; LightInfo arrays uint8 [n * 92].
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+
+import numpy as np
+import torch
+
+from . import _lib
+from .synth import FrameInputs, SCENE_DTYPE
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: torch.Tensor | None) -> C.c_void_p:
+    if t is None:
+        return C.c_void_p(0)
+    assert t.is_cuda and t.is_contiguous(), "passes take contiguous device tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def to_device_f16(bits: np.ndarray, device) -> torch.Tensor:
+    """binary16 bit patterns (uint16) -> float16 device tensor of the same shape."""
+    return torch.from_numpy(np.ascontiguousarray(bits).view(np.float16)).to(device)
+
+
+def f16_bits(t: torch.Tensor) -> np.ndarray:
+    """float16 device tensor -> uint16 bit patterns on the host."""
+    return t.detach().cpu().numpy().view(np.uint16)
+
+
+@dataclasses.dataclass
+class DeviceFrame:
+    """A frame's inputs resident in HBM (what the geometry / shadow passes would have left there)."""
+    width: int
+    rows: int
+    albedo: torch.Tensor
+    normal: torch.Tensor
+    arm: torch.Tensor
+    position: torch.Tensor
+    scene: np.ndarray
+    lights: torch.Tensor
+    n_lights: int
+    dir_shadow: torch.Tensor
+    cube_shadow: torch.Tensor
+    irradiance: torch.Tensor
+    prefilter: torch.Tensor
+    brdf_lut: torch.Tensor
+    background: torch.Tensor | None = None
+
+    @staticmethod
+    def upload(f: FrameInputs, device) -> "DeviceFrame":
+        lights = torch.from_numpy(np.frombuffer(f.lights.tobytes(), dtype=np.uint8).copy()).to(device)
+        return DeviceFrame(
+            f.width, f.height,
+            to_device_f16(f.albedo, device), to_device_f16(f.normal, device),
+            to_device_f16(f.arm, device), to_device_f16(f.position, device),
+            f.scene, lights, len(f.lights),
+            torch.from_numpy(f.dir_shadow).to(device), torch.from_numpy(f.cube_shadow).to(device),
+            to_device_f16(f.irradiance, device), to_device_f16(f.prefilter, device), to_device_f16(f.brdf_lut, device))
+
+
+def _scene_struct(scene: np.ndarray) -> _lib.SceneInfo:
+    assert scene.dtype == SCENE_DTYPE
+    return _lib.SceneInfo.from_buffer_copy(scene.tobytes())
+
+
+def shade(f: DeviceFrame, out_color: torch.Tensor, out_threshold: torch.Tensor) -> None:
+    """Composition pass (composition.frag + one light.frag draw per light) over the frame's rows."""
+    lib = _lib.load()
+    a = _lib.ShadeArgs()
+    a.width, a.rows = f.width, f.rows
+    a.albedo, a.normal, a.arm, a.position = _ptr(f.albedo), _ptr(f.normal), _ptr(f.arm), _ptr(f.position)
+    a.background = _ptr(f.background)
+    a.scene = _scene_struct(f.scene)
+    a.lights, a.n_lights, a.coverage_mode = _ptr(f.lights), f.n_lights, _lib.COVERAGE_FULLSCREEN
+    a.dir_shadow, a.dir_res = _ptr(f.dir_shadow), f.dir_shadow.shape[-1]
+    a.cube_shadow, a.cube_res = _ptr(f.cube_shadow), f.cube_shadow.shape[-1]
+    a.irradiance, a.irr_res = _ptr(f.irradiance), f.irradiance.shape[1]
+    a.prefilter, a.pref_res = _ptr(f.prefilter), f.prefilter.shape[1]
+    a.brdf_lut, a.lut_res = _ptr(f.brdf_lut), f.brdf_lut.shape[0]
+    a.out_color, a.out_threshold = _ptr(out_color), _ptr(out_threshold)
+    _lib.check(lib.vkr_shade(C.byref(a), _stream()))
+
+
+def bloom_blur(src: torch.Tensor, dst: torch.Tensor, horizontal: bool, wrap: int, *,
+               rows: int | None = None, src_row_offset: int = 0,
+               clamp_lo: int | None = None, clamp_hi: int | None = None) -> None:
+    """One bloom_blur.frag draw.  Defaults blur a whole image onto an image of the same size."""
+    lib = _lib.load()
+    a = _lib.BloomArgs()
+    a.src, a.dst = _ptr(src), _ptr(dst)
+    a.width = src.shape[1]
+    a.rows = dst.shape[0] if rows is None else rows
+    a.src_rows, a.src_row_offset = src.shape[0], src_row_offset
+    a.horizontal, a.wrap = int(bool(horizontal)), wrap
+    n = a.width if horizontal else a.src_rows
+    a.clamp_lo = 0 if clamp_lo is None else clamp_lo
+    a.clamp_hi = n - 1 if clamp_hi is None else clamp_hi
+    _lib.check(lib.vkr_bloom_blur(C.byref(a), _stream()))
+
+
+def postprocess(hdr: torch.Tensor, bloom: torch.Tensor, out: torch.Tensor, flags: int = 0) -> None:
+    lib = _lib.load()
+    _lib.check(lib.vkr_postprocess(_ptr(hdr), _ptr(bloom), _ptr(out), hdr.shape[1], hdr.shape[0], flags, _stream()))
+
+
+def bloomv_postprocess(bloom1: torch.Tensor, hdr: torch.Tensor, out: torch.Tensor, flags: int = 0, *,
+                       src_row_offset: int = 0, clamp_lo: int | None = None, clamp_hi: int | None = None,
+                       wrap: int = _lib.WRAP_CLAMP) -> None:
+    """Bloom pass 2 fused with the post-process draw."""
+    lib = _lib.load()
+    a = _lib.BloomPostArgs()
+    a.bloom1, a.hdr, a.out_rgba8 = _ptr(bloom1), _ptr(hdr), _ptr(out)
+    a.width, a.rows = hdr.shape[1], hdr.shape[0]
+    a.src_rows, a.src_row_offset = bloom1.shape[0], src_row_offset
+    a.wrap = wrap
+    a.clamp_lo = 0 if clamp_lo is None else clamp_lo
+    a.clamp_hi = bloom1.shape[0] - 1 if clamp_hi is None else clamp_hi
+    a.flags = flags
+    _lib.check(lib.vkr_bloomv_postprocess(C.byref(a), _stream()))
+
+
+def _rows(n_rows_total: int, rows: tuple[int, int] | None) -> tuple[int, int]:
+    return (0, n_rows_total) if rows is None else rows
+
+
+def equirect_to_cube(src: torch.Tensor, src_format: int, cube: torch.Tensor, rows=None) -> None:
+    lib = _lib.load()
+    n = cube.shape[1]
+    r0, r1 = _rows(6 * n, rows)
+    _lib.check(lib.vkr_ibl_equirect_to_cube(_ptr(src), src.shape[1], src.shape[0], src_format, _ptr(cube), n, r0, r1, _stream()))
+
+
+def irradiance(env: torch.Tensor, out: torch.Tensor, order: int = _lib.IRRADIANCE_PHI_SLICES, rows=None) -> None:
+    lib = _lib.load()
+    n = out.shape[1]
+    r0, r1 = _rows(6 * n, rows)
+    _lib.check(lib.vkr_ibl_irradiance(_ptr(env), env.shape[1], _ptr(out), n, order, r0, r1, _stream()))
+
+
+def prefilter(env: torch.Tensor, out: torch.Tensor, roughness: float, rows=None) -> None:
+    lib = _lib.load()
+    n = out.shape[1]
+    r0, r1 = _rows(6 * n, rows)
+    _lib.check(lib.vkr_ibl_prefilter(_ptr(env), env.shape[1], _ptr(out), n, C.c_float(roughness), r0, r1, _stream()))
+
+
+def brdf_lut(out: torch.Tensor, rows=None) -> None:
+    lib = _lib.load()
+    n = out.shape[0]
+    r0, r1 = _rows(n, rows)
+    _lib.check(lib.vkr_ibl_brdf_lut(_ptr(out), n, r0, r1, _stream()))

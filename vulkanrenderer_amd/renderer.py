@@ -1,0 +1,217 @@
+"""Host-side mirror of the reference's renderer interface for the shading path.
+
+`HipRenderer` keeps the method names, call order and error behaviour of `Renderer.VulkanRenderer`
+(src/Renderer/VulkanRenderer.cs) for the part of a frame this package replaces, and forwards every
+call to the renderer object of libvkr_hip.so (layer 2 of include/vkr_hip.h):
+
+    UpdateSceneInfo(info)          VulkanRenderer.cs:635   per-frame 240-byte SceneInfo
+    Lights                         VulkanRenderer.cs:65    list of Light; index = shadow cube index
+    BeginFrame() / EndFrame()      VulkanRenderer.cs:286 / :320   raise if called out of order
+    CreateSkyboxCubemap(...) etc.  VulkanRenderer.cs:653,734,815,966   synchronous IBL precompute
+    WaitIdle()                     blocks until the device is idle
+
+The geometry, shadow-map and skybox draws of the reference are outside this path; their results
+enter through UploadGBuffer / UploadDirectionalShadowMap / UploadPointShadowMap / UploadBackground.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+
+import numpy as np
+
+from . import _lib
+from .synth import LIGHT_DTYPE, SCENE_DTYPE, light_volume_radius
+
+
+@dataclasses.dataclass
+class Light:
+    """Light.cs:5-27."""
+    Position: tuple
+    Color: tuple
+
+    def ToInfo(self) -> np.ndarray:
+        """Light.cs:10-18: Model = Scale(volume radius) * Translate(position)."""
+        info = np.zeros((), dtype=LIGHT_DTYPE)
+        r = light_volume_radius(self.Color)
+        m = np.diag([r, r, r, 1.0])
+        m[3, :3] = self.Position
+        info["model"] = m.astype(np.float32).ravel()
+        info["position"] = self.Position
+        info["color"] = self.Color
+        return info
+
+
+def _host_ptr(a: np.ndarray) -> C.c_void_p:
+    assert a.flags["C_CONTIGUOUS"]
+    return C.c_void_p(a.ctypes.data)
+
+
+class HipRenderer:
+    """Drop-in for the composition / bloom / post-process part of VulkanRenderer.EndFrame and for the
+    IBL precompute of its constructor, running on one MI355X."""
+
+    MaxFramesInFlight = 2  # VulkanRenderer.cs:60
+    MaxLights = 32         # VulkanRenderer.cs:63
+
+    def __init__(self, width: int = 1920, height: int = 1080, *, device: int = 0, max_lights: int = 0,
+                 dir_shadow_res: int = 0, point_shadow_res: int = 0, env_res: int = 0, irradiance_res: int = 0,
+                 prefilter_res: int = 0, prefilter_mips: int = 0, brdf_lut_res: int = 0, srgb_target: bool = False):
+        self._lib = _lib.load()
+        cfg = _lib.Config(device=device, width=width, height=height, max_lights=max_lights,
+                          dir_shadow_res=dir_shadow_res, point_shadow_res=point_shadow_res, env_res=env_res,
+                          irradiance_res=irradiance_res, prefilter_res=prefilter_res, prefilter_mips=prefilter_mips,
+                          brdf_lut_res=brdf_lut_res, frames_in_flight=self.MaxFramesInFlight,
+                          flags=_lib.POST_SRGB_TARGET if srgb_target else 0)
+        self._ctx = C.c_void_p()
+        _lib.check(self._lib.vkr_create(C.byref(cfg), C.byref(self._ctx)))
+        self.width, self.height = width, height
+        self.max_lights = max_lights or self.MaxLights
+        self.dir_shadow_res = dir_shadow_res or 1024
+        self.point_shadow_res = point_shadow_res or 256
+        self.env_res = env_res or 512
+        self.irradiance_res = irradiance_res or 32
+        self.prefilter_res = prefilter_res or 128
+        self.prefilter_mips = prefilter_mips or 5
+        self.brdf_lut_res = brdf_lut_res or 512
+        self.Lights: list[Light] = []
+
+    # ---- lifetime (IDisposable in the reference) ----------------------------------------------
+    def Dispose(self) -> None:
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self._lib.vkr_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        self.Dispose()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.Dispose()
+
+    def _call(self, fn, *args):
+        if not self._ctx.value:
+            raise _lib.VkrError(_lib.VKR_ERR_INVALID, "renderer is disposed")
+        return _lib.check(fn(self._ctx, *args))
+
+    # ---- per-frame interface --------------------------------------------------------------------
+    @property
+    def CurrentFrame(self) -> int:
+        return self._call(self._lib.vkr_current_frame)
+
+    def UpdateSceneInfo(self, scene_info: np.ndarray) -> None:
+        assert scene_info.dtype == SCENE_DTYPE
+        s = _lib.SceneInfo.from_buffer_copy(scene_info.tobytes())
+        self._call(self._lib.vkr_update_scene_info, C.byref(s))
+
+    def BeginFrame(self) -> None:
+        self._call(self._lib.vkr_begin_frame)
+
+    def EndFrame(self) -> None:
+        """Uploads the light list (draw order = list order), then runs composition, bloom 1, bloom 2 and
+        post-process for the current frame and advances the frame index."""
+        self._set_lights()
+        self._call(self._lib.vkr_end_frame)
+
+    def _set_lights(self) -> None:
+        infos = np.zeros(len(self.Lights), dtype=LIGHT_DTYPE)
+        for i, light in enumerate(self.Lights):
+            infos[i] = light.ToInfo()
+        self.SetLightInfos(infos)
+
+    def SetLightInfos(self, infos: np.ndarray) -> None:
+        assert infos.dtype == LIGHT_DTYPE
+        infos = np.ascontiguousarray(infos)
+        self._call(self._lib.vkr_set_lights, _host_ptr(infos) if len(infos) else C.c_void_p(0), len(infos), _lib.COVERAGE_FULLSCREEN)
+
+    def WaitIdle(self) -> None:
+        self._call(self._lib.vkr_sync)
+
+    def Resize(self, width: int, height: int) -> None:
+        """RecreateSwapchain (VulkanRenderer.cs:1087-1127): every frame-sized image is recreated."""
+        self._call(self._lib.vkr_resize, width, height)
+        self.width, self.height = width, height
+
+    # ---- inputs produced by passes outside this path -------------------------------------------
+    def UploadGBuffer(self, albedo, normal, arm, position) -> None:
+        imgs = [np.ascontiguousarray(a) for a in (albedo, normal, arm, position)]
+        for a in imgs:
+            assert a.dtype == np.uint16 and a.shape == (self.height, self.width, 4)
+        self._call(self._lib.vkr_upload_gbuffer, *[_host_ptr(a) for a in imgs])
+
+    def UploadBackground(self, rgba16f: np.ndarray | None) -> None:
+        if rgba16f is None:
+            self._call(self._lib.vkr_upload_background, C.c_void_p(0))
+        else:
+            a = np.ascontiguousarray(rgba16f)
+            assert a.dtype == np.uint16 and a.shape == (self.height, self.width, 4)
+            self._call(self._lib.vkr_upload_background, _host_ptr(a))
+
+    def UploadDirectionalShadowMap(self, depth: np.ndarray) -> None:
+        a = np.ascontiguousarray(depth, dtype=np.float32)
+        assert a.shape == (self.dir_shadow_res, self.dir_shadow_res)
+        self._call(self._lib.vkr_upload_dir_shadow, _host_ptr(a))
+
+    def UploadPointShadowMap(self, light: int, depth_cube: np.ndarray) -> None:
+        a = np.ascontiguousarray(depth_cube, dtype=np.float32)
+        assert a.shape == (6, self.point_shadow_res, self.point_shadow_res)
+        self._call(self._lib.vkr_upload_point_shadow, light, _host_ptr(a))
+
+    # ---- IBL precompute (constructor work in the reference, VulkanRenderer.cs:271-275) ----------
+    def CreateSkyboxCubemap(self, equirect: np.ndarray) -> None:
+        a = np.ascontiguousarray(equirect)
+        fmt = _lib.SRC_RGBA8_SRGB if a.dtype == np.uint8 else _lib.SRC_RGBA16F
+        assert a.ndim == 3 and a.shape[2] == 4 and a.dtype in (np.uint8, np.uint16)
+        self._call(self._lib.vkr_create_skybox_cubemap, _host_ptr(a), a.shape[1], a.shape[0], fmt)
+
+    def UploadEnvironmentCubemap(self, cube: np.ndarray) -> None:
+        a = np.ascontiguousarray(cube)
+        assert a.dtype == np.uint16 and a.shape == (6, self.env_res, self.env_res, 4)
+        self._call(self._lib.vkr_upload_env_cube, _host_ptr(a))
+
+    def CreateIrradianceCubemap(self, order: int = _lib.IRRADIANCE_PHI_SLICES) -> None:
+        self._call(self._lib.vkr_create_irradiance_cubemap, order)
+
+    def CreatePrefilteredCubemap(self) -> None:
+        self._call(self._lib.vkr_create_prefiltered_cubemap)
+
+    def CreateBRDFLUTTexture(self) -> None:
+        self._call(self._lib.vkr_create_brdf_lut)
+
+    # ---- single passes (RenderStage's begin / draw / end shape collapses to one call each) ------
+    def CompositionPass(self) -> None:
+        self._set_lights()
+        self._call(self._lib.vkr_pass_composition)
+
+    def BloomPass(self, horizontal: bool) -> None:
+        self._call(self._lib.vkr_pass_bloom, int(bool(horizontal)))
+
+    def PostProcessPass(self) -> None:
+        self._call(self._lib.vkr_pass_postprocess)
+
+    # ---- read-back -------------------------------------------------------------------------------
+    def Read(self, target: int, frame: int = 0, mip: int = 0) -> np.ndarray:
+        if target <= _lib.TARGET_BLOOM2:
+            out = np.empty((self.height, self.width, 4), dtype=np.uint16)
+        elif target == _lib.TARGET_LDR:
+            out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        elif target == _lib.TARGET_ENV:
+            out = np.empty((6, self.env_res, self.env_res, 4), dtype=np.uint16)
+        elif target == _lib.TARGET_IRRADIANCE:
+            out = np.empty((6, self.irradiance_res, self.irradiance_res, 4), dtype=np.uint16)
+        elif target == _lib.TARGET_PREFILTER:
+            n = self.prefilter_res >> mip
+            out = np.empty((6, n, n, 4), dtype=np.uint16)
+        elif target == _lib.TARGET_BRDF_LUT:
+            out = np.empty((self.brdf_lut_res, self.brdf_lut_res, 2), dtype=np.uint16)
+        else:
+            raise _lib.VkrError(_lib.VKR_ERR_INVALID, f"unknown target {target}")
+        self._call(self._lib.vkr_read, frame, target, mip, _host_ptr(out), out.nbytes)
+        return out
+
+    def Timing(self) -> dict:
+        t = _lib.Timing()
+        self._call(self._lib.vkr_get_timing, C.byref(t))
+        return {"shade_ms": t.shade_ms, "bloom_h_ms": t.bloom_h_ms, "bloom_v_post_ms": t.bloom_v_post_ms, "frame_ms": t.frame_ms}

@@ -1,0 +1,244 @@
+"""Seeded synthetic inputs for the shading path: a G-buffer, lights, shadow maps and IBL images
+of the shapes the reference's geometry / shadow passes would hand to the composition pass
+(gpass.frag:16-24 for the G-buffer channels, point_shadow.frag:12-14 for the cube depth encoding
+length/25, Program.cs:84,125-132 for the default camera and directional light).
+
+Everything is generated with numpy from a seed, and every stored value is already rounded to the
+storage format (binary16 for RGBA16F images), so a CPU checker and the GPU see identical bits.
+"""
+from __future__ import annotations
+
+import dataclasses
+import numpy as np
+
+FAR_PLANE = 25.0
+
+
+def _f16(a: np.ndarray) -> np.ndarray:
+    """float array -> binary16 bit patterns (round to nearest even)."""
+    return np.ascontiguousarray(a.astype(np.float16)).view(np.uint16)
+
+
+def _smooth_field(rng: np.random.Generator, n: int, cells: int = 16, count: int = 1) -> np.ndarray:
+    """`count` smooth random n x n fields in [0,1]: a (cells+1)^2 random grid, bilinearly upsampled."""
+    g = rng.random((count, cells + 1, cells + 1), dtype=np.float32)
+    t = (np.arange(n, dtype=np.float32) + 0.5) / n * cells
+    i0 = np.minimum(t.astype(np.int64), cells - 1)
+    fr = t - i0
+    a = np.zeros((n, cells + 1), dtype=np.float32)
+    a[np.arange(n), i0] = 1.0 - fr
+    a[np.arange(n), i0 + 1] = fr
+    return np.einsum("ik,ckl,jl->cij", a, g, a, optimize=True).astype(np.float32)
+
+
+def look_at(eye, target, up) -> np.ndarray:
+    """Right-handed look-at matrix in the row-vector convention of Silk.NET's Matrix4X4.CreateLookAt."""
+    eye, target, up = (np.asarray(v, dtype=np.float64) for v in (eye, target, up))
+    z = eye - target
+    z /= np.linalg.norm(z)
+    x = np.cross(up, z)
+    x /= np.linalg.norm(x)
+    y = np.cross(z, x)
+    m = np.eye(4)
+    m[:3, 0], m[:3, 1], m[:3, 2] = x, y, z
+    m[3, :3] = [-x @ eye, -y @ eye, -z @ eye]
+    return m
+
+
+def ortho_off_center(left, right, bottom, top, near, far) -> np.ndarray:
+    """Matrix4X4.CreateOrthographicOffCenter (row-vector convention, depth 0..1)."""
+    m = np.eye(4)
+    m[0, 0] = 2.0 / (right - left)
+    m[1, 1] = 2.0 / (top - bottom)
+    m[2, 2] = 1.0 / (near - far)
+    m[3, 0] = (left + right) / (left - right)
+    m[3, 1] = (top + bottom) / (bottom - top)
+    m[3, 2] = near / (near - far)
+    return m
+
+
+def light_volume_radius(color) -> float:
+    """Light.cs:20-26."""
+    return 16.0 * float(np.sqrt(np.float32(max(color)) / np.float32(5.0)))
+
+
+SCENE_DTYPE = np.dtype([
+    ("camera_view", np.float32, 16), ("camera_projection", np.float32, 16),
+    ("camera_position", np.float32, 3), ("_pad0", np.float32),
+    ("dir_light_direction", np.float32, 3), ("_pad1", np.float32),
+    ("dir_light_color", np.float32, 3), ("_pad2", np.float32),
+    ("light_space_matrix", np.float32, 16)])
+LIGHT_DTYPE = np.dtype([
+    ("model", np.float32, 16), ("position", np.float32, 3), ("_pad0", np.float32), ("color", np.float32, 3)])
+assert SCENE_DTYPE.itemsize == 240 and LIGHT_DTYPE.itemsize == 92  # VulkanRenderer.cs:11-28
+
+
+def default_scene_info() -> np.ndarray:
+    """SceneInfo of the reference's demo frame (Program.cs:84,120-132)."""
+    s = np.zeros((), dtype=SCENE_DTYPE)
+    cam = (2.0, 1.0, -4.0)
+    s["camera_view"] = look_at(cam, (0, 0, 0), (0, 1, 0)).astype(np.float32).ravel()
+    s["camera_projection"] = np.eye(4, dtype=np.float32).ravel()  # not read by the shading path
+    s["camera_position"] = cam
+    s["dir_light_direction"] = (2.0, -4.0, 1.0)
+    s["dir_light_color"] = (0.35, 0.25, 0.2)
+    view = look_at((-2.0, 4.0, -1.0), (0, 0, 0), (0, 1, 0))
+    proj = ortho_off_center(-10.0, 10.0, 10.0, -10.0, 1.0, 7.5)
+    s["light_space_matrix"] = (view @ proj).astype(np.float32).ravel()
+    return s
+
+
+def make_lights(rng: np.random.Generator, n: int) -> np.ndarray:
+    """n LightInfo records: positions over the scene, colours hue * U[1,8] (so every light volume,
+    radius 16*sqrt(max/5) >= 7.15, contains the whole scene and the camera)."""
+    lights = np.zeros(n, dtype=LIGHT_DTYPE)
+    pos = np.stack([rng.uniform(-3, 3, n), rng.uniform(0.5, 3, n), rng.uniform(-3, 3, n)], axis=1)
+    hue = rng.uniform(0.2, 1.0, (n, 3))
+    hue /= hue.max(axis=1, keepdims=True)
+    col = hue * rng.uniform(1.0, 8.0, (n, 1))
+    for i in range(n):
+        r = light_volume_radius(col[i])
+        m = np.diag([r, r, r, 1.0])
+        m[3, :3] = pos[i]
+        lights[i]["model"] = m.astype(np.float32).ravel()
+    lights["position"] = pos.astype(np.float32)
+    lights["color"] = col.astype(np.float32)
+    return lights
+
+
+@dataclasses.dataclass
+class FrameInputs:
+    width: int
+    height: int
+    albedo: np.ndarray      # uint16 [H, W, 4] binary16 bits
+    normal: np.ndarray
+    arm: np.ndarray
+    position: np.ndarray
+    scene: np.ndarray       # SCENE_DTYPE scalar
+    lights: np.ndarray      # LIGHT_DTYPE [L]
+    dir_shadow: np.ndarray  # float32 [R, R]
+    cube_shadow: np.ndarray  # float32 [L, 6, S, S]
+    irradiance: np.ndarray  # uint16 [6, n, n, 4]
+    prefilter: np.ndarray   # uint16 [6, n, n, 4]
+    brdf_lut: np.ndarray    # uint16 [n, n, 2]
+
+    def rows(self, y0: int, y1: int) -> "FrameInputs":
+        """The same frame restricted to rows [y0, y1) (strips share everything but the G-buffer)."""
+        return dataclasses.replace(
+            self, height=y1 - y0,
+            albedo=np.ascontiguousarray(self.albedo[y0:y1]), normal=np.ascontiguousarray(self.normal[y0:y1]),
+            arm=np.ascontiguousarray(self.arm[y0:y1]), position=np.ascontiguousarray(self.position[y0:y1]))
+
+
+def make_gbuffer(rng: np.random.Generator, width: int, height: int, background_fraction: float = 0.1):
+    """Height field y = 0.3 sin(1.7x) cos(1.3z) over [-3,3]^2, one texel per pixel; 8x8-pixel blocks of
+    constant material with smooth variation on top; ~10% of the blocks are background (cleared texels,
+    alpha 0: VulkanRenderer.cs:1155-1161)."""
+    u = (np.arange(width, dtype=np.float32) + 0.5) / width
+    v = (np.arange(height, dtype=np.float32) + 0.5) / height
+    px = (-3.0 + 6.0 * u)[None, :].repeat(height, 0)
+    pz = (-3.0 + 6.0 * v)[:, None].repeat(width, 1)
+    py = 0.3 * np.sin(1.7 * px) * np.cos(1.3 * pz)
+    dydx = 0.3 * 1.7 * np.cos(1.7 * px) * np.cos(1.3 * pz)
+    dydz = -0.3 * 1.3 * np.sin(1.7 * px) * np.sin(1.3 * pz)
+    n = np.stack([-dydx, np.ones_like(dydx), -dydz], axis=-1)
+    n /= np.linalg.norm(n, axis=-1, keepdims=True)
+    n *= (0.9 + 0.2 * u)[None, :, None]  # deliberately not unit length: the shader renormalises
+
+    bw, bh = (width + 7) // 8, (height + 7) // 8
+
+    def blocks(lo, hi, ch):
+        b = rng.uniform(lo, hi, (bh, bw, ch)).astype(np.float32)
+        return b.repeat(8, 0).repeat(8, 1)[:height, :width]
+
+    smooth = _smooth_field(rng, max(width, height), 8, 1)[0][:height, :width]
+    albedo = np.clip(blocks(0.05, 0.95, 3) * (0.85 + 0.3 * smooth[..., None]), 0.0, 1.0)
+    ao = blocks(0.5, 1.0, 1)[..., 0]
+    rough = np.clip(blocks(0.05, 1.0, 1)[..., 0] * (0.9 + 0.2 * smooth), 0.03, 1.0)
+    metal = np.where(blocks(0.0, 1.0, 1)[..., 0] > 0.7, 1.0, 0.0) * (0.8 + 0.2 * smooth)
+    bg = (rng.random((bh, bw)) < background_fraction).repeat(8, 0).repeat(8, 1)[:height, :width]
+
+    def rgba(rgb, a):
+        out = np.concatenate([rgb, np.broadcast_to(np.asarray(a, dtype=np.float32), rgb.shape[:2])[..., None]], axis=-1)
+        out = np.where(bg[..., None], 0.0, out).astype(np.float32)
+        return _f16(out)
+
+    return (rgba(albedo, 1.0), rgba(n, 1.0), rgba(np.stack([ao, rough, metal], -1), 1.0),
+            rgba(np.stack([px, py, pz], -1), 1.0))
+
+
+def make_cube_shadows(rng: np.random.Generator, n_lights: int, res: int) -> np.ndarray:
+    """Per light a depth cube holding distance/25 with distance = 3 + 2*smooth noise."""
+    out = np.empty((n_lights, 6, res, res), dtype=np.float32)
+    for i in range(n_lights):
+        out[i] = (3.0 + 2.0 * _smooth_field(rng, res, 12, 6)) / FAR_PLANE
+    return out
+
+
+def make_dir_shadow(rng: np.random.Generator, res: int) -> np.ndarray:
+    return (0.2 + 0.7 * _smooth_field(rng, res, 24, 1)[0]).astype(np.float32)
+
+
+def make_env_cube(rng: np.random.Generator, n: int, sun_peak: float = 50.0) -> np.ndarray:
+    """RGBA16F environment cube [6, n, n, 4]: sky gradient + three Gaussian suns + smooth noise."""
+    s = (2.0 * (np.arange(n, dtype=np.float32) + 0.5) / n - 1.0)
+    ss, tt = np.meshgrid(s, s)  # ss varies along i (x), tt along j (y)
+    one = np.ones_like(ss)
+    dirs = [(one, -tt, -ss), (-one, -tt, ss), (ss, one, tt), (ss, -one, -tt), (ss, -tt, one), (-ss, -tt, -one)]
+    suns = rng.normal(size=(3, 3))
+    suns /= np.linalg.norm(suns, axis=1, keepdims=True)
+    sun_col = rng.uniform(0.5, 1.0, (3, 3))
+    noise = _smooth_field(rng, n, 8, 6)
+    out = np.empty((6, n, n, 4), dtype=np.float32)
+    for f, (x, y, z) in enumerate(dirs):
+        inv = 1.0 / np.sqrt(x * x + y * y + z * z)
+        x, y, z = x * inv, y * inv, z * inv
+        sky = 0.15 + 0.6 * np.clip(0.5 + 0.5 * y, 0, 1)
+        rgb = np.stack([sky * 0.7, sky * 0.85, sky * 1.1], -1) * (0.9 + 0.2 * noise[f][..., None])
+        for k in range(3):
+            c = x * suns[k, 0] + y * suns[k, 1] + z * suns[k, 2]
+            rgb += sun_peak * np.exp((c - 1.0) * 400.0)[..., None] * sun_col[k]
+        out[f, ..., :3] = rgb
+        out[f, ..., 3] = 1.0
+    return _f16(out)
+
+
+def make_smooth_cube(rng: np.random.Generator, n: int, lo: float, hi: float) -> np.ndarray:
+    """A smooth RGBA16F cube with values in [lo, hi] (stand-in for an irradiance / prefiltered cube)."""
+    out = np.ones((6, n, n, 4), dtype=np.float32)
+    for c in range(3):
+        out[..., c] = lo + (hi - lo) * _smooth_field(rng, n, 4, 6)
+    return _f16(out)
+
+
+def make_smooth_lut(rng: np.random.Generator, n: int) -> np.ndarray:
+    """A smooth RG16F image with the rough shape of the split-sum LUT (scale falls, bias small)."""
+    a = 0.3 + 0.7 * _smooth_field(rng, n, 4, 1)[0]
+    b = 0.2 * _smooth_field(rng, n, 4, 1)[0]
+    return _f16(np.stack([a, b], -1))
+
+
+def make_equirect(rng: np.random.Generator, w: int, h: int, hdr: bool) -> np.ndarray:
+    """Equirectangular source: RGBA16F bits [h, w, 4] (hdr) or RGBA8 [h, w, 4] (the reference's 8-bit skybox)."""
+    f = _smooth_field(rng, max(w, h), 16, 3)[:, :h, :w]
+    rgb = np.stack([f[0], f[1], f[2]], -1)
+    if hdr:
+        rgb = rgb * 4.0
+        return _f16(np.concatenate([rgb, np.ones((h, w, 1), np.float32)], -1))
+    return np.ascontiguousarray(np.concatenate([np.round(rgb * 255.0), np.full((h, w, 1), 255.0)], -1).astype(np.uint8))
+
+
+def make_frame(seed: int, width: int, height: int, n_lights: int, cube_res: int, dir_res: int,
+               irr_res: int = 32, pref_res: int = 128, lut_res: int = 512,
+               ibl: tuple | None = None) -> FrameInputs:
+    """One frame's worth of inputs.  `ibl` = (irradiance, prefilter, brdf_lut) to use precomputed IBL
+    images instead of smooth stand-ins."""
+    rng = np.random.default_rng(seed)
+    albedo, normal, arm, position = make_gbuffer(rng, width, height)
+    lights = make_lights(rng, n_lights)
+    dir_shadow = make_dir_shadow(rng, dir_res)
+    cube_shadow = make_cube_shadows(rng, n_lights, cube_res)
+    if ibl is None:
+        ibl = (make_smooth_cube(rng, irr_res, 0.2, 1.5), make_smooth_cube(rng, pref_res, 0.1, 3.0), make_smooth_lut(rng, lut_res))
+    return FrameInputs(width, height, albedo, normal, arm, position, default_scene_info(), lights,
+                       dir_shadow, cube_shadow, ibl[0], ibl[1], ibl[2])
