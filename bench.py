@@ -1,0 +1,230 @@
+"""Benchmark of the shading path: Mpixels/s for deferred PBR shading + bloom + ACES at 4K with 64
+shadowed point lights (BASELINE.json's metric, config "3840x2160, 64 point lights with 1024^2 cube
+shadow maps + 4K directional PCF shadow"), plus the IBL precompute time.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one frame through composition -> bloom 1 -> (halo exchange) -> bloom 2 + post-process on
+inputs already resident in HBM.  With N > 1 every rank owns a 3840x2160 strip of a 3840 x (2160 N)
+frame (weak scaling); strips swap 4 bloom rows with their neighbours over RCCL and the RGBA8 strips
+are gathered on rank 0 inside the timed region.  Rank 0 prints one JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT, LIGHTS, CUBE_RES, DIR_RES = 3840, 2160, 64, 1024, 4096
+SEED = 0x5EED0003
+PEAK_FP32_TFLOPS = 157.3   # MI355X FP32 vector peak
+PEAK_HBM_GBS = 8000.0      # MI355X HBM3E peak
+OPS_PER_PIXEL = 504        # canonical FP32 ops per pixel outside the light loop
+OPS_PER_PIXEL_LIGHT = 810  # canonical FP32 ops per (pixel, light) pair
+
+
+def build_inputs(rank: int, device, rows: int, n_lights: int, cube_res: int, dir_res: int):
+    """Replicated scene data from SEED, this rank's G-buffer strip from SEED + 1000 + rank; IBL images
+    computed on the GPU by the library from a synthetic environment (reference sizes 512/32/128/512)."""
+    import torch
+    from vulkanrenderer_amd import _lib, passes as P, synth
+
+    rng = np.random.default_rng(SEED)
+    lights = synth.make_lights(rng, n_lights)
+    dir_shadow = synth.make_dir_shadow(rng, dir_res)
+    cube_shadow = synth.make_cube_shadows(rng, n_lights, cube_res)
+    env = P.to_device_f16(synth.make_env_cube(rng, 512, sun_peak=20.0), device)
+    irr = torch.empty((6, 32, 32, 4), dtype=torch.float16, device=device)
+    pre = torch.empty((6, 128, 128, 4), dtype=torch.float16, device=device)
+    lut = torch.empty((512, 512, 2), dtype=torch.float16, device=device)
+    P.irradiance(env, irr, _lib.IRRADIANCE_PHI_SLICES)
+    P.prefilter(env, pre, 0.0)
+    P.brdf_lut(lut)
+    torch.cuda.synchronize()
+    albedo, normal, arm, position = synth.make_gbuffer(np.random.default_rng(SEED + 1000 + rank), WIDTH, rows)
+    f = synth.FrameInputs(WIDTH, rows, albedo, normal, arm, position, synth.default_scene_info(), lights,
+                          dir_shadow, cube_shadow, P.f16_bits(irr), P.f16_bits(pre), P.f16_bits(lut))
+    return f, P.DeviceFrame.upload(f, device)
+
+
+def time_ibl(device) -> dict:
+    """IBL precompute at the BASELINE configuration: 4096x2048 HDR equirect -> 2048^2 cube ->
+    irradiance 64^2, 5-mip GGX prefilter (128^2 .. 8^2, 1024 samples) and 512^2 BRDF LUT."""
+    import torch
+    from vulkanrenderer_amd import _lib, passes as P, synth
+
+    rng = np.random.default_rng(SEED + 4)
+    src = P.to_device_f16(synth.make_equirect(rng, 4096, 2048, hdr=True), device)
+    env = torch.empty((6, 2048, 2048, 4), dtype=torch.float16, device=device)
+    irr = torch.empty((6, 64, 64, 4), dtype=torch.float16, device=device)
+    pres = [torch.empty((6, 128 >> m, 128 >> m, 4), dtype=torch.float16, device=device) for m in range(5)]
+    lut = torch.empty((512, 512, 2), dtype=torch.float16, device=device)
+
+    def run():
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        ev[0].record()
+        P.equirect_to_cube(src, _lib.SRC_RGBA16F, env)
+        ev[1].record()
+        P.irradiance(env, irr, _lib.IRRADIANCE_PHI_SLICES)
+        ev[2].record()
+        for m in range(5):
+            P.prefilter(env, pres[m], m / 4.0)
+        ev[3].record()
+        P.brdf_lut(lut)
+        ev[4].record()
+        torch.cuda.synchronize()
+        return [ev[i].elapsed_time(ev[i + 1]) for i in range(4)]
+
+    run()
+    t = run()
+    return {"equirect_ms": round(t[0], 3), "irradiance_ms": round(t[1], 3), "prefilter_ms": round(t[2], 3),
+            "brdf_lut_ms": round(t[3], 3), "total_ms": round(sum(t), 3),
+            "config": "equirect 4096x2048 RGBA16F -> env 2048^2, irradiance 64^2, prefilter 128^2 x5 mips, LUT 512^2"}
+
+
+def cpu_baseline(f, gpu_color, gpu_thr, sample_rows: int) -> dict:
+    """The oracle (CPU restatement, OpenMP) on the first `sample_rows` rows of the same frame; also
+    checks the GPU's rows against it bit for bit."""
+    from tests import oracle
+    sub = f.rows(0, sample_rows)
+    t0 = time.perf_counter()
+    color, thr = oracle.shade(sub)
+    b1 = oracle.bloom_blur(thr, True, oracle.WRAP_REPEAT)
+    b2 = oracle.bloom_blur(b1, False, oracle.WRAP_CLAMP)
+    oracle.postprocess(color, b2)
+    dt = time.perf_counter() - t0
+    exact = bool(np.array_equal(color, gpu_color[:sample_rows]) and np.array_equal(thr, gpu_thr[:sample_rows]))
+    return {"value": round(sample_rows * f.width / dt / 1e6, 4), "unit": "Mpixels/s", "cores": oracle.omp_threads(),
+            "kind": "port", "sample": f"rows 0..{sample_rows} of the {f.width}x{f.height} frame, {len(f.lights)} lights "
+                                      f"(composition + bloom x2 + postprocess), {dt:.2f} s wall",
+            "gpu_rows_bit_exact": exact}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--lights", type=int, default=LIGHTS)
+    ap.add_argument("--cube-res", type=int, default=CUBE_RES)
+    ap.add_argument("--dir-res", type=int, default=DIR_RES)
+    ap.add_argument("--cpu-rows", type=int, default=360, help="rows of the frame the CPU baseline shades (0 = skip)")
+    ap.add_argument("--no-ibl", action="store_true", help="skip the IBL precompute timing")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from vulkanrenderer_amd import _lib
+    from vulkanrenderer_amd.strips import StripPlan, StripRenderer
+
+    _lib.load()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    f, dev_frame = build_inputs(rank, device, HEIGHT, args.lights, args.cube_res, args.dir_res)
+    plan = StripPlan.make(rank, world, HEIGHT * world)
+    renderer = StripRenderer(plan, WIDTH, device=device)
+
+    def step():
+        renderer.render(dev_frame)
+        if world > 1:
+            renderer.gather(0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel durations with HIP events on the launch stream (separate loop, same inputs)
+    names = ["shade", "bloom_h", "bloomv_post"]
+    acc = {n: 0.0 for n in names}
+    be = renderer.backend
+    lo, hi = (4, 4 + plan.rows - 1)
+    for _ in range(args.steps):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
+        be.shade(dev_frame, renderer.color, renderer.threshold)
+        ev[1].record()
+        be.bloom_h(renderer.threshold, renderer.bloom1, plan.rows)
+        ev[2].record()
+        be.bloomv_post(renderer.bloom1, renderer.color, renderer.ldr, lo, hi)
+        ev[3].record()
+        torch.cuda.synchronize()
+        for i, n in enumerate(names):
+            acc[n] += ev[i].elapsed_time(ev[i + 1])
+    kernel_ms = {n: acc[n] / args.steps for n in names}
+    barrier()
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    px = WIDTH * HEIGHT
+    ms_per_step = elapsed / args.steps * 1e3
+    flops = (OPS_PER_PIXEL + OPS_PER_PIXEL_LIGHT * args.lights) * px
+    shade_tflops = flops / (kernel_ms["shade"] * 1e-3) / 1e12
+    out = {
+        "metric": "Mpixels/s deferred PBR+bloom+ACES @4K 64 shadowed lights",
+        "value": round(px * world / (elapsed / args.steps) / 1e6, 3),
+        "unit": "Mpixels/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{WIDTH}x{HEIGHT} strip per GPU ({WIDTH}x{HEIGHT * world} frame), {args.lights} point lights with "
+                               f"{args.cube_res}^2 cube shadow maps + {args.dir_res}^2 directional PCF shadow; composition + bloom x2 + ACES/gamma",
+                   "parallelism": f"strips{world}", "storage": "RGBA16F targets, RGBA8 output"},
+        "roofline": {"bound": "valu", "kernel": "shade_kernel", "achieved": round(shade_tflops, 3), "peak": PEAK_FP32_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(shade_tflops / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                     "algorithmic": f"({OPS_PER_PIXEL} + {OPS_PER_PIXEL_LIGHT} x {args.lights}) FP32 ops x {px} pixels per launch",
+                     "avg_launch_ms": round(kernel_ms["shade"], 4)},
+        "roofline_post": [
+            {"bound": "hbm", "kernel": "bloom_h_kernel", "achieved": round(16 * px / (kernel_ms["bloom_h"] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
+             "unit": "GB/s", "frac": round(16 * px / (kernel_ms["bloom_h"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "avg_launch_ms": round(kernel_ms["bloom_h"], 4),
+             "algorithmic": "16 B/pixel"},
+            {"bound": "hbm", "kernel": "bloom_v_kernel<fused post>", "achieved": round(20 * px / (kernel_ms["bloomv_post"] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
+             "unit": "GB/s", "frac": round(20 * px / (kernel_ms["bloomv_post"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "avg_launch_ms": round(kernel_ms["bloomv_post"], 4),
+             "algorithmic": "20 B/pixel (8 bloom-1 + 8 colour in, 4 RGBA8 out)"}],
+    }
+    if not args.no_ibl:
+        out["ibl_precompute"] = time_ibl(device)
+    if world == 1 and args.cpu_rows > 0:
+        from vulkanrenderer_amd import passes as P
+        out["cpu_baseline"] = cpu_baseline(f, P.f16_bits(renderer.color), P.f16_bits(renderer.threshold), args.cpu_rows)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,132 @@
+"""Strip-parallel frame chain: one process per GPU, the frame cut into horizontal strips.
+
+The reference renders on one device; nothing in it partitions a frame.  The shading path shards
+naturally by rows: the composition pass and the post-process draw are per-pixel, bloom pass 1
+(horizontal, REPEAT) is per-row, and bloom pass 2 (vertical, CLAMP_TO_EDGE) reads 4 rows above and
+below each output row.  So each rank shades its strip, blurs it horizontally, swaps 4 boundary rows
+of the pass-1 image with its neighbours (point-to-point over RCCL / xGMI, or gloo on CPU), and
+finishes with the fused vertical-blur + tonemap kernel.  There is no reduction anywhere, so the
+assembled image is bit-identical to a single-GPU run.
+
+Scene constants, lights, shadow maps and IBL images are replicated; only the G-buffer is split.
+"""
+from __future__ import annotations
+
+import dataclasses
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+HALO = 4  # bloom_blur.frag:20-23 reaches 4 texels to each side
+
+
+@dataclasses.dataclass(frozen=True)
+class StripPlan:
+    """Rows [row0, row0 + rows) of a `total_rows`-row frame belong to `rank`."""
+    rank: int
+    world: int
+    total_rows: int
+    row0: int
+    rows: int
+
+    @staticmethod
+    def make(rank: int, world: int, total_rows: int) -> "StripPlan":
+        per = -(-total_rows // world)
+        row0 = min(rank * per, total_rows)
+        rows = min(per, total_rows - row0)
+        if rows < HALO:
+            raise ValueError(f"strip of rank {rank} has {rows} rows; every strip needs at least {HALO}")
+        return StripPlan(rank, world, total_rows, row0, rows)
+
+    @property
+    def is_top(self) -> bool:
+        return self.rank == 0
+
+    @property
+    def is_bottom(self) -> bool:
+        return self.rank == self.world - 1
+
+
+class HipBackend:
+    """The product backend: libvkr_hip.so passes on torch CUDA tensors."""
+
+    def __init__(self, device):
+        from . import passes
+        _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("the strip renderer needs a GPU: there is no CPU path")
+        self.P = passes
+        self.device = device
+
+    def empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def shade(self, frame, color, thr):
+        self.P.shade(frame, color, thr)
+
+    def bloom_h(self, thr, bloom1, rows):
+        # writes rows [HALO, HALO + rows) of the halo-padded pass-1 image
+        self.P.bloom_blur(thr, bloom1[HALO:HALO + rows], True, _lib.WRAP_REPEAT, rows=rows)
+
+    def bloomv_post(self, bloom1, hdr, out, lo, hi):
+        self.P.bloomv_postprocess(bloom1, hdr, out, 0, src_row_offset=HALO, clamp_lo=lo, clamp_hi=hi)
+
+
+class StripRenderer:
+    """Runs the per-frame chain on this rank's strip.  `backend` defaults to the HIP kernels."""
+
+    def __init__(self, plan: StripPlan, width: int, device=None, backend=None, group=None):
+        self.plan, self.width, self.group = plan, width, group
+        self.backend = backend if backend is not None else HipBackend(device)
+        r = plan.rows
+        self.color = self.backend.empty((r, width, 4), torch.float16)
+        self.threshold = self.backend.empty((r, width, 4), torch.float16)
+        self.bloom1 = self.backend.empty((r + 2 * HALO, width, 4), torch.float16)
+        self.ldr = self.backend.empty((r, width, 4), torch.uint8)
+
+    def exchange_halo(self) -> None:
+        """Rows HALO..2*HALO go to the rank above, the last HALO real rows to the rank below."""
+        p, r = self.plan, self.plan.rows
+        if p.world == 1:
+            return
+        ops = []
+        if not p.is_top:
+            ops.append(dist.P2POp(dist.isend, self.bloom1[HALO:2 * HALO], p.rank - 1, self.group))
+            ops.append(dist.P2POp(dist.irecv, self.bloom1[0:HALO], p.rank - 1, self.group))
+        if not p.is_bottom:
+            ops.append(dist.P2POp(dist.isend, self.bloom1[r:r + HALO], p.rank + 1, self.group))
+            ops.append(dist.P2POp(dist.irecv, self.bloom1[r + HALO:r + 2 * HALO], p.rank + 1, self.group))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+    def render(self, frame) -> torch.Tensor:
+        """composition -> bloom 1 -> halo exchange -> bloom 2 + post-process; returns the RGBA8 strip."""
+        p, r = self.plan, self.plan.rows
+        self.backend.shade(frame, self.color, self.threshold)
+        self.backend.bloom_h(self.threshold, self.bloom1, r)
+        self.exchange_halo()
+        # frame edges clamp (CLAMP_TO_EDGE); interior strip edges read the neighbours' rows
+        lo = HALO if p.is_top else 0
+        hi = HALO + r - 1 if p.is_bottom else r + 2 * HALO - 1
+        self.backend.bloomv_post(self.bloom1, self.color, self.ldr, lo, hi)
+        return self.ldr
+
+    def gather(self, dst: int = 0):
+        """Collects the RGBA8 strips on rank `dst` (list of tensors there, None elsewhere)."""
+        p = self.plan
+        if p.world == 1:
+            return [self.ldr]
+        if p.rank == dst:
+            per = -(-p.total_rows // p.world)
+            parts = [torch.empty((min(per, p.total_rows - k * per), self.width, 4), dtype=torch.uint8, device=self.ldr.device)
+                     for k in range(p.world)]
+            ops = [dist.P2POp(dist.irecv, parts[k], k, self.group) for k in range(p.world) if k != dst]
+            parts[dst] = self.ldr
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+            return parts
+        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, self.ldr, dst, self.group)]):
+            req.wait()
+        return None
