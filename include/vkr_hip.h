@@ -229,6 +229,17 @@ typedef struct VkrTiming {
 } VkrTiming;
 VKR_EXPORT int32_t vkr_get_timing(vkr_ctx *ctx, VkrTiming *out);
 
+/* ------------------------------------------------------------------------------------------
+ * Diagnostics
+ * ------------------------------------------------------------------------------------------ */
+
+/* Sweeps all 2^32 binary32 patterns on the current device and counts where the kernels' fast
+ * correctly rounded 1/x and sqrt(x) differ from IEEE division / square root.  counts7[0..4] are
+ * mismatch counts (rcp one Newton step, rcp two steps, sqrt, rcp of the IEEE sqrt,
+ * the sqrt + reciprocal pair as shipped); counts7[5..6] the number of patterns tested for rcp and
+ * for sqrt.  No counterpart in the reference: it backs the bit-exactness claim of the kernels. */
+VKR_EXPORT int32_t vkr_selftest_math(uint64_t *counts7);
+
 #ifdef __cplusplus
 }
 #endif

@@ -118,6 +118,7 @@ PROTOTYPES = {
     "vkr_read": [_vp, _i32, _i32, _i32, _vp, C.c_int64],
     "vkr_sync": [_vp],
     "vkr_get_timing": [_vp, C.POINTER(Timing)],
+    "vkr_selftest_math": [C.POINTER(C.c_uint64)],
 }
 
 _lib = None
