@@ -1,0 +1,84 @@
+"""The C-ABI library loads and exports every symbol include/vkr_hip.h declares, with the struct
+layouts the reference's parameter blocks have.  No compute calls: this runs without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+from vulkanrenderer_amd import _lib, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "vkr_hip.h")).read()
+    return sorted(set(re.findall(r"VKR_EXPORT\s+(?:const\s+char\s*\*|int32_t)\s*(vkr_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 30
+    for name in names:
+        assert hasattr(lib, name), f"{name} is declared in vkr_hip.h but not exported by libvkr_hip.so"
+    # and the ctypes prototypes cover the header
+    assert set(_lib.PROTOTYPES) | {"vkr_last_error"} == set(names)
+
+
+def test_struct_layouts_match_the_reference_blocks():
+    # VulkanRenderer.cs:11-28: SceneInfo offsets 0/64/128/144/160/176 (240 B), LightInfo 0/64/80 (92 B)
+    s = _lib.SceneInfo
+    assert (s.camera_view.offset, s.camera_projection.offset, s.camera_position.offset,
+            s.dir_light_direction.offset, s.dir_light_color.offset, s.light_space_matrix.offset) == (0, 64, 128, 144, 160, 176)
+    assert C.sizeof(s) == 240
+    li = _lib.LightInfo
+    assert (li.model.offset, li.position.offset, li.color.offset) == (0, 64, 80) and C.sizeof(li) == 92
+    assert synth.SCENE_DTYPE.itemsize == 240 and synth.LIGHT_DTYPE.itemsize == 92
+    assert synth.SCENE_DTYPE.fields["light_space_matrix"][1] == 176 and synth.LIGHT_DTYPE.fields["color"][1] == 80
+
+
+def test_version_and_argument_errors_without_a_device():
+    lib = _lib.load()
+    assert lib.vkr_abi_version() == 1
+    assert lib.vkr_device_count() >= 0
+    # argument validation happens before any HIP call
+    assert lib.vkr_shade(None, None) == _lib.VKR_ERR_INVALID
+    assert b"null" in lib.vkr_last_error()
+    a = _lib.BloomArgs()
+    assert lib.vkr_bloom_blur(C.byref(a), None) == _lib.VKR_ERR_INVALID
+    assert lib.vkr_postprocess(None, None, None, 4, 4, 0, None) == _lib.VKR_ERR_INVALID
+    assert lib.vkr_ibl_brdf_lut(None, 8, 0, 8, None) == _lib.VKR_ERR_INVALID
+    assert lib.vkr_create(None, None) == _lib.VKR_ERR_INVALID
+    try:
+        _lib.check(lib.vkr_begin_frame(None))
+    except _lib.VkrError as e:
+        assert e.code == _lib.VKR_ERR_INVALID
+    else:
+        raise AssertionError("vkr_begin_frame(NULL) must fail")
+
+
+def test_light_to_info_matches_light_cs():
+    # Light.cs:10-26: Model = Scale(16*sqrt(max/5)) * Translate(position)
+    from vulkanrenderer_amd.renderer import Light
+    info = Light((1.0, 2.0, 3.0), (0.0, 5.0, 1.0)).ToInfo()
+    m = info["model"].reshape(4, 4)
+    assert np.allclose(np.diag(m)[:3], 16.0) and m[3, 3] == 1.0
+    assert tuple(m[3, :3]) == (1.0, 2.0, 3.0)
+    assert tuple(info["position"]) == (1.0, 2.0, 3.0) and tuple(info["color"]) == (0.0, 5.0, 1.0)
+    assert synth.light_volume_radius((1.0, 0.2, 0.1)) == np.float32(16 * np.sqrt(np.float32(0.2)))
+
+
+def test_synthetic_inputs_are_deterministic_and_binary16_exact():
+    a = synth.make_frame(5, 40, 24, 3, 8, 16, irr_res=4, pref_res=4, lut_res=8)
+    b = synth.make_frame(5, 40, 24, 3, 8, 16, irr_res=4, pref_res=4, lut_res=8)
+    for name in ("albedo", "normal", "arm", "position", "dir_shadow", "cube_shadow", "irradiance", "prefilter", "brdf_lut"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    assert a.albedo.dtype == np.uint16 and a.albedo.shape == (24, 40, 4)
+    alpha = a.albedo.view(np.float16)[..., 3]
+    assert set(np.unique(alpha)) <= {0.0, 1.0}
+    # background texels are fully cleared
+    bg = alpha == 0
+    assert (a.normal[bg] == 0).all() and (a.position[bg] == 0).all()
+    strip = a.rows(8, 16)
+    assert strip.height == 8 and np.array_equal(strip.albedo, a.albedo[8:16])

@@ -1,0 +1,106 @@
+"""Strip partition over torch.distributed: world_size 2 and 3 on the gloo backend (CPU).
+
+The product backend launches HIP kernels, which need a GPU; here the per-strip passes are supplied
+by the CPU oracle instead, so what is under test is the distribution logic of
+vulkanrenderer_amd.strips -- row split, halo rows and their direction, clamp ranges at the frame
+edges, the gather -- by comparing the assembled image with a single whole-frame run bit for bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from vulkanrenderer_amd import synth
+from vulkanrenderer_amd.strips import HALO, StripPlan, StripRenderer
+
+W, H, LIGHTS = 48, 37, 2
+
+
+class OracleBackend:
+    """Same interface as strips.HipBackend, on CPU tensors, computed by the oracle."""
+
+    def empty(self, shape, dtype):
+        return torch.zeros(shape, dtype=dtype)
+
+    @staticmethod
+    def _bits(t):
+        return t.numpy().view(np.uint16)
+
+    def shade(self, frame, color, thr):
+        from tests import oracle
+        c, t = oracle.shade(frame)
+        self._bits(color)[...] = c
+        self._bits(thr)[...] = t
+
+    def bloom_h(self, thr, bloom1, rows):
+        from tests import oracle
+        self._bits(bloom1)[HALO:HALO + rows] = oracle.bloom_blur(self._bits(thr), True, oracle.WRAP_REPEAT)
+
+    def bloomv_post(self, bloom1, hdr, out, lo, hi):
+        from tests import oracle
+        b = self._bits(bloom1)
+        rows = hdr.shape[0]
+        # vertical blur of output row r centred on source row r + HALO, taps clamped to [lo, hi]
+        idx = np.clip(np.arange(-4, rows + 4) + HALO, lo, hi)
+        padded = np.ascontiguousarray(b[idx])                       # rows + 8 rows, edges already clamped
+        b2 = oracle.bloom_blur(padded, False, oracle.WRAP_CLAMP)[4:4 + rows]
+        out.numpy()[...] = oracle.postprocess(self._bits(hdr), np.ascontiguousarray(b2))
+
+
+def _frame():
+    return synth.make_frame(77, W, H, LIGHTS, 16, 64, irr_res=4, pref_res=8, lut_res=16)
+
+
+def _worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        f = _frame()
+        plan = StripPlan.make(rank, world, H)
+        r = StripRenderer(plan, W, backend=OracleBackend())
+        r.render(f.rows(plan.row0, plan.row0 + plan.rows))
+        parts = r.gather(0)
+        if rank == 0:
+            np.save(out_path, torch.cat(parts, 0).numpy())
+        else:
+            assert parts is None
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_strips_reassemble_to_the_single_device_image(world, tmp_path, oracle):
+    want = oracle.frame_chain(_frame())["ldr"]
+    out_path = str(tmp_path / "ldr.npy")
+    mp.spawn(_worker, args=(world, _free_port(), out_path), nprocs=world, join=True)
+    got = np.load(out_path)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+
+
+def test_strip_plan_covers_the_frame():
+    for total, world in [(2160, 8), (37, 3), (16, 4), (17, 4)]:
+        plans = [StripPlan.make(r, world, total) for r in range(world)]
+        assert plans[0].row0 == 0 and sum(p.rows for p in plans) == total
+        for a, b in zip(plans, plans[1:]):
+            assert a.row0 + a.rows == b.row0
+        assert plans[0].is_top and plans[-1].is_bottom
+    with pytest.raises(ValueError):
+        StripPlan.make(3, 4, 13)  # 13 rows over 4 ranks leaves 3-row strips: thinner than the bloom halo
+
+
+def test_single_rank_needs_no_process_group(oracle):
+    f = _frame()
+    r = StripRenderer(StripPlan.make(0, 1, H), W, backend=OracleBackend())
+    ldr = r.render(f).numpy()
+    assert np.array_equal(ldr, oracle.frame_chain(f)["ldr"])
+    assert r.gather(0)[0] is r.ldr

@@ -21,7 +21,7 @@ static constexpr float INV_PI = 1.0f / PI_F;
 static constexpr float LUM_R = 0.2126f, LUM_G = 0.7152f, LUM_B = 0.0722f;
 
 struct ShadeParams {
-    int width, rows;
+    int width, rows, tiles_x, tiles_y;
     const uint2 *albedo, *normal, *arm, *position, *background;
     const float *lights;  // VkrLightInfo array viewed as floats, 23 floats per light
     int n_lights;
@@ -121,8 +121,11 @@ VKR_DEV void lut_sample(const uint32_t *lut, int n, float s, float t, float &o0,
 VKR_DEV int face_texel(float c, float ima, float fres, int res)
 {
     float s = fma_(c * ima, 0.5f, 0.5f);
-    int i = (int)__builtin_floorf(s * fres);
-    return min(max(i, 0), res - 1);
+    int i, r;
+    // floor + convert in one instruction, clamp to [0, res-1] in one instruction
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(i) : "v"(s * fres));
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(i), "s"(res - 1));
+    return r;
 }
 
 // Number of the 20 taps whose stored depth is closer than `cur` when every tap of every lane of
@@ -240,12 +243,33 @@ VKR_DEV int common_face(const float (&X)[3], const float (&Y)[3], const float (&
     return face + (neg ? 1 : 0);
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin by id, and each XCD has its own L2.  This maps
+// block id -> tile so that each XCD shades one contiguous run of tiles, ordered in 16-tile-wide
+// column blocks: the workgroups resident on an XCD at one time cover a compact screen region and
+// therefore a compact region of every shadow map, which keeps their shared texels in that L2.
+VKR_DEV void tile_of_block(unsigned b, int tiles_x, int tiles_y, int &tx, int &ty)
+{
+    const unsigned total = (unsigned)tiles_x * tiles_y;
+    const unsigned xcd = b & 7u, q = b >> 3;
+    // ids 0..total-1 dealt round-robin: XCD k owns ceil((total - k) / 8) of them
+    const unsigned base = total >> 3, rem = total & 7u;
+    const unsigned v = xcd * base + min(xcd, rem) + q;  // position in the column-block order
+    const unsigned block_tiles = 16u * (unsigned)tiles_y;
+    const unsigned cb = min(v / block_tiles, (unsigned)(tiles_x - 1) / 16u);
+    const unsigned r = v - cb * block_tiles;
+    const unsigned cbw = min(16u, (unsigned)tiles_x - cb * 16u);
+    ty = (int)(r / cbw);
+    tx = (int)(cb * 16u + r % cbw);
+}
+
 __global__ __launch_bounds__(256) void shade_kernel(const ShadeParams p)
 {
     // 16x16 pixel tile per workgroup; wave w covers the 8x8 block (w & 1, w >> 1) of the tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    int tile_x, tile_y;
+    tile_of_block(blockIdx.x, p.tiles_x, p.tiles_y, tile_x, tile_y);
+    const int x = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int y = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
     if (x >= p.width || y >= p.rows) return;
     const size_t px = (size_t)y * p.width + x;
 
@@ -413,7 +437,8 @@ extern "C" int32_t vkr_shade(const VkrShadeArgs *a, void *stream)
     }
     for (int i = 0; i < 16; i++) p.light_space[i] = a->scene.light_space_matrix[i];
 
-    dim3 grid((a->width + 15) / 16, (a->rows + 15) / 16);
-    hipLaunchKernelGGL(shade_kernel, grid, dim3(256), 0, as_stream(stream), p);
+    p.tiles_x = (a->width + 15) / 16; p.tiles_y = (a->rows + 15) / 16;
+    VKR_REQUIRE((int64_t)p.tiles_x * p.tiles_y < (1ll << 31), "vkr_shade: strip too large");
+    hipLaunchKernelGGL(shade_kernel, dim3((unsigned)(p.tiles_x * p.tiles_y)), dim3(256), 0, as_stream(stream), p);
     return launch_status("vkr_shade");
 }

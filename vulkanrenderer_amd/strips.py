@@ -33,9 +33,9 @@ class StripPlan:
 
     @staticmethod
     def make(rank: int, world: int, total_rows: int) -> "StripPlan":
-        per = -(-total_rows // world)
-        row0 = min(rank * per, total_rows)
-        rows = min(per, total_rows - row0)
+        base, extra = divmod(total_rows, world)  # the first `extra` strips are one row taller
+        row0 = rank * base + min(rank, extra)
+        rows = base + (1 if rank < extra else 0)
         if rows < HALO:
             raise ValueError(f"strip of rank {rank} has {rows} rows; every strip needs at least {HALO}")
         return StripPlan(rank, world, total_rows, row0, rows)
@@ -119,8 +119,7 @@ class StripRenderer:
         if p.world == 1:
             return [self.ldr]
         if p.rank == dst:
-            per = -(-p.total_rows // p.world)
-            parts = [torch.empty((min(per, p.total_rows - k * per), self.width, 4), dtype=torch.uint8, device=self.ldr.device)
+            parts = [torch.empty((StripPlan.make(k, p.world, p.total_rows).rows, self.width, 4), dtype=torch.uint8, device=self.ldr.device)
                      for k in range(p.world)]
             ops = [dist.P2POp(dist.irecv, parts[k], k, self.group) for k in range(p.world) if k != dst]
             parts[dst] = self.ldr
