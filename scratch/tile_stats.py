@@ -42,7 +42,7 @@ for li in range(0, L, 8):
     uni = (f_lo == f_hi) & (f_lo >= 0) & anyvalid
     for lim in (32, 48, 64, 96, 128):
         res.setdefault(lim, []).append(((span <= lim) & uni).sum() / max(anyvalid.sum(), 1))
-    for lim in (2048, 4096, 6144, 8192):
+    for lim in (1024, 1536, 2048, 2496, 4096, 6144, 8192):
         res.setdefault("area%d" % lim, []).append(((area <= lim) & uni).sum() / max(anyvalid.sum(), 1))
     res.setdefault("mean_area_fit4096", []).append(area[(area <= 4096) & uni].mean())
     res.setdefault("uniform", []).append(uni.sum() / max(anyvalid.sum(), 1))

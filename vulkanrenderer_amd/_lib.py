@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvkr_hip.so")
+# VKR_HIP_LIB selects another build of the same library (kernel experiments); default: the in-tree one
+LIB_PATH = os.environ.get("VKR_HIP_LIB") or os.path.join(_HERE, "libvkr_hip.so")
 
 VKR_OK = 0
 VKR_ERR_INVALID, VKR_ERR_HIP, VKR_ERR_UNSUPPORTED, VKR_ERR_ORDER, VKR_ERR_NO_DEVICE = -1, -2, -3, -4, -5

@@ -85,6 +85,7 @@ class StripRenderer:
         self.threshold = self.backend.empty((r, width, 4), torch.float16)
         self.bloom1 = self.backend.empty((r + 2 * HALO, width, 4), torch.float16)
         self.ldr = self.backend.empty((r, width, 4), torch.uint8)
+        self._gathered = None  # receive buffers of gather(), allocated on first use
 
     def exchange_halo(self) -> None:
         """Rows HALO..2*HALO go to the rank above, the last HALO real rows to the rank below."""
@@ -119,8 +120,10 @@ class StripRenderer:
         if p.world == 1:
             return [self.ldr]
         if p.rank == dst:
-            parts = [torch.empty((StripPlan.make(k, p.world, p.total_rows).rows, self.width, 4), dtype=torch.uint8, device=self.ldr.device)
-                     for k in range(p.world)]
+            if self._gathered is None:
+                self._gathered = [self.backend.empty((StripPlan.make(k, p.world, p.total_rows).rows, self.width, 4), torch.uint8)
+                                  for k in range(p.world)]
+            parts = list(self._gathered)
             ops = [dist.P2POp(dist.irecv, parts[k], k, self.group) for k in range(p.world) if k != dst]
             parts[dst] = self.ldr
             for req in dist.batch_isend_irecv(ops):
