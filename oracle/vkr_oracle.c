@@ -5,11 +5,16 @@
  * it exists so that tests, the smoke check and the benchmark's cpu_baseline leg have an
  * independent result to compare the HIP kernels with.
  *
- * PARITY UNPINNED: the reference ships no tests, golden images or known-answer vectors for this
- * path, and neither its C# host code (needs .NET 8 + NuGet packages) nor its shaders (need a
- * Vulkan driver) can run in the build container.  This restatement is therefore checked against
- * closed-form known answers and against an interpreter run of the reference's own SPIR-V
- * binaries (see tests/golden/), not against reference test fixtures.
+ * Pinning.  The reference ships no tests, golden images or known-answer vectors for this path,
+ * and neither its C# host code (needs .NET 8 + NuGet packages) nor a Vulkan driver is available
+ * in the build container.  What the reference does ship is its compiled shaders
+ * (compiled_shaders/*.frag.spv): tools/spirv_interp.py executes those binaries on small seeded
+ * inputs with the reference's sampler / blend / attachment state, tools/make_golden.py stores the
+ * inputs and outputs under tests/golden/, and tests/test_golden_reference_spirv.py holds this file
+ * to them.  The fixed-function steps a Vulkan driver performs for the reference (texture
+ * filtering, cube face selection, blending, binary16 conversion) are in no reference file; they are
+ * restated from the Vulkan specification here and, independently, in the interpreter's samplers.
+ * Closed-form known answers are in tests/test_oracle_kat.py.
  *
  * Source files restated (paths relative to the reference checkout):
  *   src/Renderer/Shaders/composition.frag:30-168      orc_shade (directional + ambient part)
