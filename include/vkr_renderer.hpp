@@ -1,0 +1,116 @@
+// vkr_renderer.hpp -- C++ host-side mirror of the reference's renderer interface for the shading
+// path, over the C ABI of vkr_hip.h.  Header-only; link against libvkr_hip.so.
+//
+// The reference drives this path from C# (src/Renderer/VulkanRenderer.cs); where its toolchain is
+// not available this class plays the same role with the same method names, call order and error
+// behaviour (every non-success status becomes an exception, as the reference throws on any
+// non-Success VkResult):
+//
+//   UpdateSceneInfo(info)        VulkanRenderer.cs:635
+//   Lights                       VulkanRenderer.cs:65   (draw order = list order)
+//   BeginFrame() / EndFrame()    VulkanRenderer.cs:286 / :320
+//   CreateSkyboxCubemap() ...    VulkanRenderer.cs:653, :734, :815, :966
+//   WaitIdle(), Dispose (RAII)   as in the reference's IDisposable wrappers
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "vkr_hip.h"
+
+namespace vkr {
+
+struct Error : std::runtime_error {
+    int32_t code;
+    Error(int32_t c, const std::string &what) : std::runtime_error(what), code(c) {}
+};
+
+inline void check(int32_t rc)
+{
+    if (rc < 0) throw Error(rc, std::string("libvkr_hip: ") + vkr_last_error());
+}
+
+// Light.cs:5-27
+struct Light {
+    float Position[3];
+    float Color[3];
+
+    float CalculateVolumeSize() const  // Light.cs:20-26
+    {
+        float m = Color[0] > Color[1] ? Color[0] : Color[1];
+        m = m > Color[2] ? m : Color[2];
+        return 16.0f * std::sqrt(m / 5.0f);
+    }
+    VkrLightInfo ToInfo() const  // Light.cs:10-18: Model = Scale(volume) * Translate(position), row-vector convention
+    {
+        VkrLightInfo info{};
+        const float r = CalculateVolumeSize();
+        info.model[0] = info.model[5] = info.model[10] = r;
+        info.model[15] = 1.0f;
+        for (int i = 0; i < 3; i++) {
+            info.model[12 + i] = Position[i];
+            info.position[i] = Position[i];
+            info.color[i] = Color[i];
+        }
+        return info;
+    }
+};
+
+class HipRenderer {
+public:
+    std::vector<Light> Lights;  // VulkanRenderer.cs:65
+
+    explicit HipRenderer(const VkrConfig &config) { check(vkr_create(&config, &ctx_)); }
+    ~HipRenderer() { Dispose(); }
+    HipRenderer(const HipRenderer &) = delete;
+    HipRenderer &operator=(const HipRenderer &) = delete;
+
+    void Dispose()
+    {
+        if (ctx_) { vkr_destroy(ctx_); ctx_ = nullptr; }
+    }
+
+    void UpdateSceneInfo(const VkrSceneInfo &info) { check(vkr_update_scene_info(ctx_, &info)); }
+    void BeginFrame() { check(vkr_begin_frame(ctx_)); }
+    void EndFrame()
+    {
+        std::vector<VkrLightInfo> infos;
+        infos.reserve(Lights.size());
+        for (const Light &l : Lights) infos.push_back(l.ToInfo());
+        check(vkr_set_lights(ctx_, infos.data(), (int32_t)infos.size(), VKR_COVERAGE_FULLSCREEN));
+        check(vkr_end_frame(ctx_));
+    }
+    void WaitIdle() { check(vkr_sync(ctx_)); }
+    void Resize(int32_t width, int32_t height) { check(vkr_resize(ctx_, width, height)); }  // RecreateSwapchain
+    int32_t CurrentFrame() const { return vkr_current_frame(ctx_); }
+
+    // results of the passes outside this path (geometry, shadow maps, skybox)
+    void UploadGBuffer(const void *albedo, const void *normal, const void *arm, const void *position)
+    {
+        check(vkr_upload_gbuffer(ctx_, albedo, normal, arm, position));
+    }
+    void UploadBackground(const void *rgba16f_or_null) { check(vkr_upload_background(ctx_, rgba16f_or_null)); }
+    void UploadDirectionalShadowMap(const float *depth) { check(vkr_upload_dir_shadow(ctx_, depth)); }
+    void UploadPointShadowMap(int32_t light, const float *depth_cube) { check(vkr_upload_point_shadow(ctx_, light, depth_cube)); }
+
+    // IBL precompute (VulkanRenderer.cs:271-275)
+    void CreateSkyboxCubemap(const void *equirect, int32_t w, int32_t h, int32_t format) { check(vkr_create_skybox_cubemap(ctx_, equirect, w, h, format)); }
+    void UploadEnvironmentCubemap(const void *cube) { check(vkr_upload_env_cube(ctx_, cube)); }
+    void CreateIrradianceCubemap(int32_t order = VKR_IRRADIANCE_PHI_SLICES) { check(vkr_create_irradiance_cubemap(ctx_, order)); }
+    void CreatePrefilteredCubemap() { check(vkr_create_prefiltered_cubemap(ctx_)); }
+    void CreateBRDFLUTTexture() { check(vkr_create_brdf_lut(ctx_)); }
+
+    void Read(int32_t frame, int32_t target, int32_t mip, void *host, int64_t bytes) { check(vkr_read(ctx_, frame, target, mip, host, bytes)); }
+    VkrTiming Timing()
+    {
+        VkrTiming t{};
+        check(vkr_get_timing(ctx_, &t));
+        return t;
+    }
+
+private:
+    vkr_ctx *ctx_ = nullptr;
+};
+
+}  // namespace vkr

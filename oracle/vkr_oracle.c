@@ -8,7 +8,7 @@
  * Pinning.  The reference ships no tests, golden images or known-answer vectors for this path,
  * and neither its C# host code (needs .NET 8 + NuGet packages) nor a Vulkan driver is available
  * in the build container.  What the reference does ship is its compiled shaders
- * (compiled_shaders/*.frag.spv): tools/spirv_interp.py executes those binaries on small seeded
+ * (the .frag.spv files under compiled_shaders/): tools/spirv_interp.py executes those binaries on small seeded
  * inputs with the reference's sampler / blend / attachment state, tools/make_golden.py stores the
  * inputs and outputs under tests/golden/, and tests/test_golden_reference_spirv.py holds this file
  * to them.  The fixed-function steps a Vulkan driver performs for the reference (texture

@@ -82,3 +82,17 @@ def test_synthetic_inputs_are_deterministic_and_binary16_exact():
     assert (a.normal[bg] == 0).all() and (a.position[bg] == 0).all()
     strip = a.rows(8, 16)
     assert strip.height == 8 and np.array_equal(strip.albedo, a.albedo[8:16])
+
+
+def test_cpp_host_wrapper_compiles_against_the_header(tmp_path):
+    """include/vkr_renderer.hpp (the C++ mirror of the reference's renderer interface) is valid C++17
+    against vkr_hip.h, and vkr_hip.h is valid C."""
+    import subprocess
+    src = tmp_path / "use.cpp"
+    src.write_text('#include "vkr_renderer.hpp"\n'
+                   'int use() { VkrConfig c{}; vkr::Light l{{0,1,0},{1,5,2}}; return (int)l.ToInfo().model[0] + (int)sizeof(vkr::HipRenderer) + c.device; }\n')
+    subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", os.path.join(ROOT, "include"), str(src)], check=True)
+    csrc = tmp_path / "use.c"
+    csrc.write_text('#include "vkr_hip.h"\nint size(void) { return (int)sizeof(VkrSceneInfo) + (int)sizeof(VkrLightInfo); }\n'
+                    '_Static_assert(sizeof(VkrSceneInfo) == 240, "SceneInfo"); _Static_assert(sizeof(VkrLightInfo) == 92, "LightInfo");\n')
+    subprocess.run(["gcc", "-std=c11", "-fsyntax-only", "-Wall", "-I", os.path.join(ROOT, "include"), str(csrc)], check=True)

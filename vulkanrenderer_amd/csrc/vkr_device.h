@@ -12,6 +12,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "vkr_fastmath.h"
 
 #define VKR_DEV __device__ __forceinline__
 
@@ -34,6 +35,14 @@ VKR_DEV f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
 VKR_DEV f3 scale3(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
 VKR_DEV f3 neg3(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 VKR_DEV f3 normalize3(f3 a) { return scale3(a, rcp_rn(sqrt_rn(dot3(a, a)))); }
+// Same bits as normalize3 for every input, through the short sqrt / reciprocal sequences of
+// vkr_fastmath.h (which fall back to the IEEE ones outside their exact domain).
+VKR_DEV f3 normalize3_fast(f3 a)
+{
+    float s, inv;
+    sqrt_and_rcp_rn(dot3(a, a), s, inv);
+    return scale3(a, inv);
+}
 VKR_DEV f3 cross3(f3 a, f3 b)
 {
     return mk3(fma_(a.y, b.z, -(a.z * b.y)), fma_(a.z, b.x, -(a.x * b.z)), fma_(a.x, b.y, -(a.y * b.x)));
@@ -88,7 +97,7 @@ VKR_DEV void cube_st(f3 r, int &face, float &s, float &t)
 {
     float sc, tc, ma;
     face = cube_face(r, sc, tc, ma);
-    float ima = rcp_rn(ma);
+    float ima = rcp_rn_checked(ma);
     s = fma_(sc * ima, 0.5f, 0.5f);
     t = fma_(tc * ima, 0.5f, 0.5f);
 }

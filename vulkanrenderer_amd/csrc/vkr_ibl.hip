@@ -134,6 +134,50 @@ __global__ __launch_bounds__(64) void irradiance_kernel(const void *env, int env
     out[(size_t)row * n + i] = pack4((PI_F * ir) * inv_count, (PI_F * ig) * inv_count, (PI_F * ib) * inv_count, 1.0f);
 }
 
+// Phi-slice order, one workgroup per output texel: lane a owns phi slice a (252 of the 256 lanes),
+// sums its 63 theta samples from zero, and the slice sums are then added in phi order by one lane
+// per colour channel -- the same additions in the same order as the one-lane kernel above, spread
+// over 252 lanes.
+__global__ __launch_bounds__(256) void irradiance_slices_kernel(const void *env, int env_n, uint2 *out, int n, int nphi, int ntheta, int row_begin)
+{
+    __shared__ float part[3][IRR_MAX_PHI];
+    const int a = threadIdx.x;
+    const int i = blockIdx.x;
+    const int row = row_begin + blockIdx.y;
+    const int f = row / n, j = row - f * n;
+    const f3 N = normalize3(face_dir(f, i, j, n));
+    const f3 right = normalize3(mk3(N.z, 0.0f, -N.x));  // normalize(cross((0,1,0), N))
+    const f3 up = normalize3(cross3(N, right));
+    if (a < nphi) {
+        const float2 pcs = g_irr_phi_cs[a];
+        float pr = 0.0f, pg = 0.0f, pb = 0.0f;
+        for (int b = 0; b < ntheta; b++) {
+            const float2 tsc = g_irr_theta_sc[b];
+            const float st = tsc.x, ct = tsc.y;
+            const float tx = st * pcs.x, ty = st * pcs.y, tz = ct;
+            const f3 sv = mk3(fma_(tz, N.x, fma_(ty, up.x, tx * right.x)),
+                              fma_(tz, N.y, fma_(ty, up.y, tx * right.y)),
+                              fma_(tz, N.z, fma_(ty, up.z, tx * right.z)));
+            const f3 c = texcube_rgb_linear(env, env_n, sv);
+            pr = fma_(c.x * ct, st, pr);
+            pg = fma_(c.y * ct, st, pg);
+            pb = fma_(c.z * ct, st, pb);
+        }
+        part[0][a] = pr; part[1][a] = pg; part[2][a] = pb;
+    }
+    __syncthreads();
+    if (a < 3) {
+        float acc = 0.0f;
+        for (int k = 0; k < nphi; k++) acc += part[a][k];
+        part[a][0] = acc;
+    }
+    __syncthreads();
+    if (a == 0) {
+        const float inv_count = rcp_rn((float)(nphi * ntheta));
+        out[(size_t)row * n + i] = pack4((PI_F * part[0][0]) * inv_count, (PI_F * part[1][0]) * inv_count, (PI_F * part[2][0]) * inv_count, 1.0f);
+    }
+}
+
 // ---- prefilter.frag / brdf.frag shared pieces -----------------------------------------------
 
 // prefilter.frag:65-73
@@ -172,11 +216,11 @@ __global__ __launch_bounds__(64) void prefilter_kernel(const void *env, int env_
         float2 pcs = g_hammersley_cs[s];
         float2 tcs = theta_cs[s];
         float hx = pcs.x * tcs.y, hy = pcs.y * tcs.y, hz = tcs.x;
-        f3 H = normalize3(mk3(fma_(N.x, hz, fma_(bitangent.x, hy, tangent.x * hx)),
-                              fma_(N.y, hz, fma_(bitangent.y, hy, tangent.y * hx)),
-                              fma_(N.z, hz, fma_(bitangent.z, hy, tangent.z * hx))));
+        f3 H = normalize3_fast(mk3(fma_(N.x, hz, fma_(bitangent.x, hy, tangent.x * hx)),
+                                   fma_(N.y, hz, fma_(bitangent.y, hy, tangent.y * hx)),
+                                   fma_(N.z, hz, fma_(bitangent.z, hy, tangent.z * hx))));
         float vh2 = 2.0f * dot3(N, H);  // V = N
-        f3 L = normalize3(mk3(fma_(vh2, H.x, -N.x), fma_(vh2, H.y, -N.y), fma_(vh2, H.z, -N.z)));
+        f3 L = normalize3_fast(mk3(fma_(vh2, H.x, -N.x), fma_(vh2, H.y, -N.y), fma_(vh2, H.z, -N.z)));
         float NdotL = max0(dot3(N, L));
         if (NdotL > 0.0f) {
             f3 c = texcube_rgb_linear(env, env_n, L);  // the shader's mip level is clamped to 0 by the sampler
@@ -209,17 +253,15 @@ __global__ __launch_bounds__(256) void brdf_lut_kernel(uint32_t *out, int n, int
         float2 tcs = theta_cs[s];
         float hx = pcs.x * tcs.y, hy = pcs.y * tcs.y, hz = tcs.x;
         // with N = (0,0,1): tangent = (0,-1,0), bitangent = (1,0,-0) (brdf.frag:52-56), so
-        // sampleVec = (hy, -hx, hz); the fma chain below is that product written out.
-        f3 H = normalize3(mk3(fma_(0.0f, hz, fma_(1.0f, hy, 0.0f * hx)),
-                              fma_(0.0f, hz, fma_(0.0f, hy, -1.0f * hx)),
-                              fma_(1.0f, hz, fma_(-0.0f, hy, 0.0f * hx))));
-        float vh = fma_(Vz, H.z, fma_(0.0f, H.y, Vx * H.x));
+        // sampleVec = (hy, -hx, hz); V.y = 0 drops out of dot(V,H) and of L.y
+        f3 H = normalize3_fast(mk3(hy, -hx, hz));
+        float vh = fma_(Vz, H.z, Vx * H.x);
         float vh2 = 2.0f * vh;
-        f3 L = normalize3(mk3(fma_(vh2, H.x, -Vx), fma_(vh2, H.y, -0.0f), fma_(vh2, H.z, -Vz)));
+        f3 L = normalize3_fast(mk3(fma_(vh2, H.x, -Vx), vh2 * H.y, fma_(vh2, H.z, -Vz)));
         float NdotL = max0(L.z), NdotH = max0(H.z), VdotH = max0(vh);
         if (NdotL > 0.0f) {
-            float G = (NdotL * rcp_rn(fma_(NdotL, 1.0f - k, k))) * gV;
-            float G_vis = (G * VdotH) * rcp_rn(NdotH * NdotV);
+            float G = (NdotL * rcp_rn_checked(fma_(NdotL, 1.0f - k, k))) * gV;
+            float G_vis = (G * VdotH) * rcp_rn_checked(NdotH * NdotV);
             float Fc = pow5(1.0f - VdotH);
             A = fma_(1.0f - Fc, G_vis, A);
             B = fma_(Fc, G_vis, B);
@@ -263,8 +305,13 @@ extern "C" int32_t vkr_ibl_irradiance(const void *env, int32_t env_n, void *out,
     if (rc != VKR_OK) return rc;
     if ((rc = ensure_tables()) != VKR_OK) return rc;
     if (row_end == row_begin) return VKR_OK;
-    dim3 grid((n + 63) / 64, row_end - row_begin);
-    hipLaunchKernelGGL(irradiance_kernel, grid, dim3(64), 0, as_stream(stream), env, env_n, (uint2 *)out, n, order, g_irr_nphi, g_irr_ntheta, row_begin, row_end);
+    if (order == VKR_IRRADIANCE_PHI_SLICES) {
+        dim3 grid(n, row_end - row_begin);
+        hipLaunchKernelGGL(irradiance_slices_kernel, grid, dim3(256), 0, as_stream(stream), env, env_n, (uint2 *)out, n, g_irr_nphi, g_irr_ntheta, row_begin);
+    } else {
+        dim3 grid((n + 63) / 64, row_end - row_begin);
+        hipLaunchKernelGGL(irradiance_kernel, grid, dim3(64), 0, as_stream(stream), env, env_n, (uint2 *)out, n, order, g_irr_nphi, g_irr_ntheta, row_begin, row_end);
+    }
     return launch_status("vkr_ibl_irradiance");
 }
 

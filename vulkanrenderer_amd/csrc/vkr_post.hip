@@ -3,6 +3,7 @@
 // bytes per pixel and do a few dozen flops on them, so they are sized for HBM bandwidth:
 // every input texel is fetched from memory once per workgroup, 8-16 bytes per lane.
 #include "vkr_device.h"
+#include "vkr_fastmath.h"
 #include "vkr_host.h"
 
 namespace vkr {
@@ -35,6 +36,9 @@ VKR_DEV float blur9(float m4, float m3, float m2, float m1, float c, float p1, f
 // Horizontal pass.  One workgroup blurs a 512-pixel piece of one row: the piece plus a 4-pixel
 // apron on each side is staged in LDS (each global texel is read once, 16 bytes per lane), then
 // every lane produces two adjacent output pixels from five 16-byte LDS reads.
+#ifndef VKR_BH_ROWS
+#define VKR_BH_ROWS 1
+#endif
 static constexpr int BH_PIECE = 512;
 
 __global__ __launch_bounds__(256) void bloom_h_kernel(const BloomParams p)
@@ -90,8 +94,8 @@ __global__ __launch_bounds__(256) void bloom_h_kernel(const BloomParams p)
 VKR_DEV float aces(float c)
 {
     float num = c * fma_(2.51f, c, 0.03f);
-    float den = fma_(c, fma_(2.43f, c, 0.59f), 0.14f);
-    return clamp01(num * rcp_rn(den));
+    float den = fma_(c, fma_(2.43f, c, 0.59f), 0.14f);  // >= 0.14 for c >= 0: inside fast_rcp_rn's exact domain
+    return clamp01(num * (c >= 0.0f ? fast_rcp_rn(den) : rcp_rn(den)));
 }
 
 // pow(m, 1/2.2) for m in [0,1] through the hardware log2/exp2 units
@@ -116,44 +120,87 @@ VKR_DEV uint32_t tonemap_pack(float r, float g, float b, int flags)
     return out;
 }
 
-// Vertical pass, optionally fused with the post-process draw.  A workgroup owns 256 columns and
-// VR output rows; each lane walks down its column with the nine source rows of the window held
-// in registers, so a source row is fetched once per workgroup (plus the 8-row apron).
-static constexpr int VR = 24;
+// Vertical pass, optionally fused with the post-process draw.  A workgroup owns 256 * PXL columns
+// and VR output rows; each lane walks down its PXL adjacent columns with the nine source rows of the
+// window held in registers, so a source row is fetched once per workgroup (plus the 8-row apron).
+#ifndef VKR_VR
+#define VKR_VR 16
+#endif
+#ifndef VKR_PXL
+#define VKR_PXL 1
+#endif
+static constexpr int VR = VKR_VR, PXL = VKR_PXL;
+
+template <int N> struct TexelVec;
+template <> struct TexelVec<1> { typedef uint2 type; };
+template <> struct TexelVec<2> { typedef uint4 type; };
+
+VKR_DEV void unpack_n(uint2 v, rgba (&o)[1]) { o[0] = unpack4(v); }
+VKR_DEV void unpack_n(uint4 v, rgba (&o)[2]) { o[0] = unpack4(make_uint2(v.x, v.y)); o[1] = unpack4(make_uint2(v.z, v.w)); }
 
 template <bool FUSE_POST>
 __global__ __launch_bounds__(256) void bloom_v_kernel(const BloomParams p, const uint2 *hdr, uint32_t *out8, int flags)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x;
+    typedef typename TexelVec<PXL>::type vec_t;
+    const int x = (blockIdx.x * 256 + threadIdx.x) * PXL;
     if (x >= p.width) return;
+    // the vector path needs all PXL columns inside the image and 16-byte aligned rows
+    const bool vec_ok = PXL == 1 || (x + PXL <= p.width && (p.width % PXL) == 0);
     const int r0 = blockIdx.y * VR;
-    float wr[9], wg[9], wb[9];
+    float wr[9][PXL], wg[9][PXL], wb[9][PXL];
+    auto load_row = [&](int slot, int src_row) {
+        const uint2 *row = p.src + (size_t)src_row * p.width + x;
+        rgba t[PXL];
+        if (vec_ok) {
+            unpack_n(*reinterpret_cast<const vec_t *>(row), t);
+        } else {
 #pragma unroll
-    for (int kk = 0; kk < 8; kk++) {
-        int sr = wrap_index(r0 + kk - 4 + p.src_row_offset, p.src_rows, p.wrap, p.clamp_lo, p.clamp_hi);
-        rgba v = unpack4(p.src[(size_t)sr * p.width + x]);
-        wr[kk] = v.r; wg[kk] = v.g; wb[kk] = v.b;
-    }
+            for (int k = 0; k < PXL; k++) t[k] = unpack4(row[min(k, p.width - 1 - x)]);
+        }
+#pragma unroll
+        for (int k = 0; k < PXL; k++) { wr[slot][k] = t[k].r; wg[slot][k] = t[k].g; wb[slot][k] = t[k].b; }
+    };
+#pragma unroll
+    for (int kk = 0; kk < 8; kk++)
+        load_row(kk, wrap_index(r0 + kk - 4 + p.src_row_offset, p.src_rows, p.wrap, p.clamp_lo, p.clamp_hi));
 #pragma unroll
     for (int r = 0; r < VR; r++) {
         if (r0 + r >= p.rows) break;
-        {
-            int sr = wrap_index(r0 + r + 4 + p.src_row_offset, p.src_rows, p.wrap, p.clamp_lo, p.clamp_hi);
-            rgba v = unpack4(p.src[(size_t)sr * p.width + x]);
-            wr[(r + 8) % 9] = v.r; wg[(r + 8) % 9] = v.g; wb[(r + 8) % 9] = v.b;
-        }
-#define W_(arr, k) arr[(r + (k)) % 9]
-        float br = blur9(W_(wr, 0), W_(wr, 1), W_(wr, 2), W_(wr, 3), W_(wr, 4), W_(wr, 5), W_(wr, 6), W_(wr, 7), W_(wr, 8));
-        float bg = blur9(W_(wg, 0), W_(wg, 1), W_(wg, 2), W_(wg, 3), W_(wg, 4), W_(wg, 5), W_(wg, 6), W_(wg, 7), W_(wg, 8));
-        float bb = blur9(W_(wb, 0), W_(wb, 1), W_(wb, 2), W_(wb, 3), W_(wb, 4), W_(wb, 5), W_(wb, 6), W_(wb, 7), W_(wb, 8));
-#undef W_
+        load_row((r + 8) % 9, wrap_index(r0 + r + 4 + p.src_row_offset, p.src_rows, p.wrap, p.clamp_lo, p.clamp_hi));
         const size_t o = (size_t)(r0 + r) * p.width + x;
+        uint32_t px8[PXL];
+        uint2 px16[PXL];
+        rgba h[PXL];
         if (FUSE_POST) {
-            // the bloom-2 attachment is RGBA16F: round before postprocess.frag reads it
-            rgba h = unpack4(hdr[o]);
-            out8[o] = tonemap_pack(h.r + round_f16(br), h.g + round_f16(bg), h.b + round_f16(bb), flags);
+            if (vec_ok) {
+                unpack_n(*reinterpret_cast<const vec_t *>(hdr + o), h);
+            } else {
+#pragma unroll
+                for (int k = 0; k < PXL; k++) h[k] = unpack4(hdr[o + min(k, p.width - 1 - x)]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PXL; k++) {
+#define W_(arr, q) arr[(r + (q)) % 9][k]
+            float br = blur9(W_(wr, 0), W_(wr, 1), W_(wr, 2), W_(wr, 3), W_(wr, 4), W_(wr, 5), W_(wr, 6), W_(wr, 7), W_(wr, 8));
+            float bg = blur9(W_(wg, 0), W_(wg, 1), W_(wg, 2), W_(wg, 3), W_(wg, 4), W_(wg, 5), W_(wg, 6), W_(wg, 7), W_(wg, 8));
+            float bb = blur9(W_(wb, 0), W_(wb, 1), W_(wb, 2), W_(wb, 3), W_(wb, 4), W_(wb, 5), W_(wb, 6), W_(wb, 7), W_(wb, 8));
+#undef W_
+            if (FUSE_POST)  // the bloom-2 attachment is RGBA16F: round before postprocess.frag reads it
+                px8[k] = tonemap_pack(h[k].r + round_f16(br), h[k].g + round_f16(bg), h[k].b + round_f16(bb), flags);
+            else
+                px16[k] = pack4(br, bg, bb, 1.0f);
+        }
+        if (FUSE_POST) {
+            if (vec_ok && PXL == 2) *reinterpret_cast<uint2 *>(out8 + o) = make_uint2(px8[0], px8[PXL - 1]);
+            else
+#pragma unroll
+                for (int k = 0; k < PXL; k++) if (x + k < p.width) out8[o + k] = px8[k];
         } else {
-            p.dst[o] = pack4(br, bg, bb, 1.0f);
+            if (vec_ok && PXL == 2) *reinterpret_cast<uint4 *>(p.dst + o) = make_uint4(px16[0].x, px16[0].y, px16[PXL - 1].x, px16[PXL - 1].y);
+            else
+#pragma unroll
+                for (int k = 0; k < PXL; k++) if (x + k < p.width) p.dst[o + k] = px16[k];
         }
     }
 }
@@ -206,7 +253,7 @@ extern "C" int32_t vkr_bloom_blur(const VkrBloomArgs *a, void *stream)
         dim3 grid((a->width + BH_PIECE - 1) / BH_PIECE, a->rows);
         hipLaunchKernelGGL(bloom_h_kernel, grid, dim3(256), 0, as_stream(stream), p);
     } else {
-        dim3 grid((a->width + 255) / 256, (a->rows + VR - 1) / VR);
+        dim3 grid((a->width + 256 * PXL - 1) / (256 * PXL), (a->rows + VR - 1) / VR);
         hipLaunchKernelGGL(bloom_v_kernel<false>, grid, dim3(256), 0, as_stream(stream), p, (const uint2 *)nullptr, (uint32_t *)nullptr, 0);
     }
     return launch_status("vkr_bloom_blur");
@@ -223,7 +270,7 @@ extern "C" int32_t vkr_bloomv_postprocess(const VkrBloomPostArgs *a, void *strea
     p.src = (const uint2 *)a->bloom1; p.dst = nullptr;
     p.width = a->width; p.rows = a->rows; p.src_rows = a->src_rows; p.src_row_offset = a->src_row_offset;
     p.wrap = a->wrap; p.clamp_lo = a->clamp_lo; p.clamp_hi = a->clamp_hi;
-    dim3 grid((a->width + 255) / 256, (a->rows + VR - 1) / VR);
+    dim3 grid((a->width + 256 * PXL - 1) / (256 * PXL), (a->rows + VR - 1) / VR);
     hipLaunchKernelGGL(bloom_v_kernel<true>, grid, dim3(256), 0, as_stream(stream), p, (const uint2 *)a->hdr, (uint32_t *)a->out_rgba8, a->flags);
     return launch_status("vkr_bloomv_postprocess");
 }
