@@ -46,7 +46,7 @@ def build_inputs(rank: int, device, rows: int, n_lights: int, cube_res: int, dir
     irr = torch.empty((6, 32, 32, 4), dtype=torch.float16, device=device)
     pre = torch.empty((6, 128, 128, 4), dtype=torch.float16, device=device)
     lut = torch.empty((512, 512, 2), dtype=torch.float16, device=device)
-    P.irradiance(env, irr, _lib.IRRADIANCE_PHI_SLICES)
+    P.irradiance(env, irr, _lib.IRRADIANCE_SEQUENTIAL)
     P.prefilter(env, pre, 0.0)
     P.brdf_lut(lut)
     torch.cuda.synchronize()
@@ -74,7 +74,7 @@ def time_ibl(device) -> dict:
         ev[0].record()
         P.equirect_to_cube(src, _lib.SRC_RGBA16F, env)
         ev[1].record()
-        P.irradiance(env, irr, _lib.IRRADIANCE_PHI_SLICES)
+        P.irradiance(env, irr, _lib.IRRADIANCE_SEQUENTIAL)
         ev[2].record()
         for m in range(5):
             P.prefilter(env, pres[m], m / 4.0)

@@ -51,6 +51,14 @@ VKR_FM_DEV float fast_sqrt_rn(float x)
     return s;
 }
 
+// RN(sqrt(x)) for every x: zero returns itself, everything else outside [2^-96, 2^96] takes the
+// compiler's IEEE sequence.
+VKR_FM_DEV float sqrt_rn_checked(float x)
+{
+    if (__builtin_expect(!(x >= 0x1p-96f && x <= 0x1p96f), 0)) return x == 0.0f ? x : __builtin_sqrtf(x);
+    return fast_sqrt_rn(x);
+}
+
 // s = RN(sqrt(x)) and RN(1/s): the pair normalize() and length() need.  Outside
 // [2^-96, 2^96] (where the fma residuals above could lose bits, and for 0 / inf / NaN) it falls
 // back to the compiler's IEEE sequences, so the pair equals sqrtf(x), 1.0f/sqrtf(x) for every x.

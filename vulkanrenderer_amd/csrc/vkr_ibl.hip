@@ -99,45 +99,65 @@ __global__ __launch_bounds__(256) void equirect_kernel(const void *src, int sw, 
 
 // ---- irradiance.frag:10-39 ------------------------------------------------------------------
 
-// One lane per output texel.  order 0: a single running sum (phi outer, theta inner), the
-// shader's own order.  order 1: every phi slice summed from zero, slice sums added in phi order.
-__global__ __launch_bounds__(64) void irradiance_kernel(const void *env, int env_n, uint2 *out, int n, int order, int nphi, int ntheta, int row_begin, int row_end)
+// The shader's own order (one running sum, phi outer, theta inner), one workgroup per output
+// texel.  The 15 876 terms are produced 16 phi slices at a time by all lanes (lane = one theta of
+// one slice) into LDS; one lane per colour channel then adds the chunk to the running sum in
+// sample order while the other waves already produce the next chunk into the second buffer.
+static constexpr int IRR_CHUNK_SLICES = 16;
+__global__ __launch_bounds__(256) void irradiance_texel_kernel(const void *env, int env_n, uint2 *out, int n, int nphi, int ntheta, int row_begin)
 {
-    int i = blockIdx.x * 64 + threadIdx.x;
-    int row = row_begin + blockIdx.y;
-    if (i >= n || row >= row_end) return;
-    int f = row / n, j = row - f * n;
-    f3 N = normalize3(face_dir(f, i, j, n));
-    f3 right = normalize3(mk3(N.z, 0.0f, -N.x));  // normalize(cross((0,1,0), N))
-    f3 up = normalize3(cross3(N, right));
-    float ir = 0.0f, ig = 0.0f, ib = 0.0f;
-    for (int a = 0; a < nphi; a++) {
-        float2 pcs = g_irr_phi_cs[a];
-        float pr = 0.0f, pg = 0.0f, pb = 0.0f;
-        if (order == VKR_IRRADIANCE_SEQUENTIAL) { pr = ir; pg = ig; pb = ib; }
-        for (int b = 0; b < ntheta; b++) {
-            float2 tsc = g_irr_theta_sc[b];
-            float st = tsc.x, ct = tsc.y;
-            float tx = st * pcs.x, ty = st * pcs.y, tz = ct;
-            f3 sv = mk3(fma_(tz, N.x, fma_(ty, up.x, tx * right.x)),
-                        fma_(tz, N.y, fma_(ty, up.y, tx * right.y)),
-                        fma_(tz, N.z, fma_(ty, up.z, tx * right.z)));
-            f3 c = texcube_rgb_linear(env, env_n, sv);
-            pr = fma_(c.x * ct, st, pr);
-            pg = fma_(c.y * ct, st, pg);
-            pb = fma_(c.z * ct, st, pb);
+    __shared__ float term[2][3][IRR_CHUNK_SLICES * IRR_MAX_THETA];
+    __shared__ float sin_theta[IRR_MAX_THETA];
+    __shared__ float result[3];
+    const int tid = threadIdx.x;
+    const int b = tid & 63, w = tid >> 6;
+    const int i = blockIdx.x;
+    const int row = row_begin + blockIdx.y;
+    const int f = row / n, j = row - f * n;
+    const f3 N = normalize3(face_dir(f, i, j, n));
+    const f3 right = normalize3(mk3(N.z, 0.0f, -N.x));  // normalize(cross((0,1,0), N))
+    const f3 up = normalize3(cross3(N, right));
+    const float2 tsc = g_irr_theta_sc[b];
+    const float st = tsc.x, ct = tsc.y;
+    if (tid < ntheta) sin_theta[tid] = g_irr_theta_sc[tid].x;
+    float acc = 0.0f;
+    for (int a0 = 0, k = 0; a0 < nphi; a0 += IRR_CHUNK_SLICES, k++) {
+        float (*buf)[IRR_CHUNK_SLICES * IRR_MAX_THETA] = term[k & 1];
+#pragma unroll
+        for (int m = 0; m < IRR_CHUNK_SLICES / 4; m++) {
+            const int al = w + 4 * m, a = a0 + al;
+            if (a < nphi && b < ntheta) {
+                const float2 pcs = g_irr_phi_cs[a];
+                const float tx = st * pcs.x, ty = st * pcs.y, tz = ct;
+                const f3 sv = mk3(fma_(tz, N.x, fma_(ty, up.x, tx * right.x)),
+                                  fma_(tz, N.y, fma_(ty, up.y, tx * right.y)),
+                                  fma_(tz, N.z, fma_(ty, up.z, tx * right.z)));
+                const f3 c = texcube_rgb_linear(env, env_n, sv);
+                const int p = al * ntheta + b;
+                buf[0][p] = c.x * ct; buf[1][p] = c.y * ct; buf[2][p] = c.z * ct;
+            }
         }
-        if (order == VKR_IRRADIANCE_SEQUENTIAL) { ir = pr; ig = pg; ib = pb; }
-        else { ir += pr; ig += pg; ib += pb; }
+        __syncthreads();
+        if (tid < 3) {
+            const int slices = min(IRR_CHUNK_SLICES, nphi - a0);
+            const float *mine = buf[tid];
+            for (int al = 0; al < slices; al++) {
+                for (int bb = 0; bb < ntheta; bb++) acc = fma_(mine[bb], sin_theta[bb], acc);
+                mine += ntheta;
+            }
+        }
     }
-    float inv_count = rcp_rn((float)(nphi * ntheta));
-    out[(size_t)row * n + i] = pack4((PI_F * ir) * inv_count, (PI_F * ig) * inv_count, (PI_F * ib) * inv_count, 1.0f);
+    if (tid < 3) result[tid] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        const float inv_count = rcp_rn((float)(nphi * ntheta));
+        out[(size_t)row * n + i] = pack4((PI_F * result[0]) * inv_count, (PI_F * result[1]) * inv_count, (PI_F * result[2]) * inv_count, 1.0f);
+    }
 }
 
 // Phi-slice order, one workgroup per output texel: lane a owns phi slice a (252 of the 256 lanes),
 // sums its 63 theta samples from zero, and the slice sums are then added in phi order by one lane
-// per colour channel -- the same additions in the same order as the one-lane kernel above, spread
-// over 252 lanes.
+// per colour channel.
 __global__ __launch_bounds__(256) void irradiance_slices_kernel(const void *env, int env_n, uint2 *out, int n, int nphi, int ntheta, int row_begin)
 {
     __shared__ float part[3][IRR_MAX_PHI];
@@ -191,45 +211,64 @@ VKR_DEV float2 ggx_theta(int s, float rough)
 {
     float a = rough * rough;
     float xi_y = radical_inverse((uint32_t)s);
-    float cos_t = sqrt_rn((1.0f - xi_y) * rcp_rn(fma_(a * a - 1.0f, xi_y, 1.0f)));
-    float sin_t = sqrt_rn(fma_(-cos_t, cos_t, 1.0f));
+    float cos_t = sqrt_rn_checked((1.0f - xi_y) * rcp_rn_checked(fma_(a * a - 1.0f, xi_y, 1.0f)));
+    float sin_t = sqrt_rn_checked(fma_(-cos_t, cos_t, 1.0f));
     return make_float2(cos_t, sin_t);
 }
 
-// prefilter.frag:21-63, one lane per output texel; the per-sample (cos theta, sin theta) pairs
-// depend only on the roughness and are built once per workgroup in LDS.
-__global__ __launch_bounds__(64) void prefilter_kernel(const void *env, int env_n, uint2 *out, int n, float rough, int row_begin, int row_end)
+// prefilter.frag:21-63, one workgroup per output texel.  Every lane evaluates four of the 1024
+// samples (environment colour and N.L) into LDS; four lanes -- red, green, blue and the weight
+// total -- then add them up in sample order, which is the shader's single running sum.
+__global__ __launch_bounds__(256) void prefilter_texel_kernel(const void *env, int env_n, uint2 *out, int n, float rough, int row_begin)
 {
-    __shared__ float2 theta_cs[SAMPLE_COUNT];
-    for (int s = threadIdx.x; s < SAMPLE_COUNT; s += 64) theta_cs[s] = ggx_theta(s, rough);
-    __syncthreads();
-    int i = blockIdx.x * 64 + threadIdx.x;
-    int row = row_begin + blockIdx.y;
-    if (i >= n || row >= row_end) return;
-    int f = row / n, j = row - f * n;
-    f3 N = normalize3(face_dir(f, i, j, n));
-    f3 tangent = __builtin_fabsf(N.z) < 0.999f ? normalize3(mk3(-N.y, N.x, 0.0f))   // cross((0,0,1), N)
-                                               : normalize3(mk3(0.0f, -N.z, N.y));  // cross((1,0,0), N)
-    f3 bitangent = cross3(N, tangent);
-    float cr = 0.0f, cg = 0.0f, cb = 0.0f, total = 0.0f;
-    for (int s = 0; s < SAMPLE_COUNT; s++) {
-        float2 pcs = g_hammersley_cs[s];
-        float2 tcs = theta_cs[s];
-        float hx = pcs.x * tcs.y, hy = pcs.y * tcs.y, hz = tcs.x;
-        f3 H = normalize3_fast(mk3(fma_(N.x, hz, fma_(bitangent.x, hy, tangent.x * hx)),
-                                   fma_(N.y, hz, fma_(bitangent.y, hy, tangent.y * hx)),
-                                   fma_(N.z, hz, fma_(bitangent.z, hy, tangent.z * hx))));
-        float vh2 = 2.0f * dot3(N, H);  // V = N
-        f3 L = normalize3_fast(mk3(fma_(vh2, H.x, -N.x), fma_(vh2, H.y, -N.y), fma_(vh2, H.z, -N.z)));
-        float NdotL = max0(dot3(N, L));
-        if (NdotL > 0.0f) {
-            f3 c = texcube_rgb_linear(env, env_n, L);  // the shader's mip level is clamped to 0 by the sampler
-            cr = fma_(c.x, NdotL, cr); cg = fma_(c.y, NdotL, cg); cb = fma_(c.z, NdotL, cb);
-            total += NdotL;
-        }
+    __shared__ __align__(16) float term[4][SAMPLE_COUNT];  // [0..2] environment colour, [3] N.L
+    __shared__ float result[4];
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x;
+    const int row = row_begin + blockIdx.y;
+    const int f = row / n, j = row - f * n;
+    const f3 N = normalize3(face_dir(f, i, j, n));
+    const f3 tangent = __builtin_fabsf(N.z) < 0.999f ? normalize3(mk3(-N.y, N.x, 0.0f))   // cross((0,0,1), N)
+                                                     : normalize3(mk3(0.0f, -N.z, N.y));  // cross((1,0,0), N)
+    const f3 bitangent = cross3(N, tangent);
+#pragma unroll
+    for (int m = 0; m < SAMPLE_COUNT / 256; m++) {
+        const int s = tid + 256 * m;
+        const float2 pcs = g_hammersley_cs[s];
+        const float2 tcs = ggx_theta(s, rough);
+        const float hx = pcs.x * tcs.y, hy = pcs.y * tcs.y, hz = tcs.x;
+        const f3 H = normalize3_fast(mk3(fma_(N.x, hz, fma_(bitangent.x, hy, tangent.x * hx)),
+                                         fma_(N.y, hz, fma_(bitangent.y, hy, tangent.y * hx)),
+                                         fma_(N.z, hz, fma_(bitangent.z, hy, tangent.z * hx))));
+        const float vh2 = 2.0f * dot3(N, H);  // V = N
+        const f3 L = normalize3_fast(mk3(fma_(vh2, H.x, -N.x), fma_(vh2, H.y, -N.y), fma_(vh2, H.z, -N.z)));
+        const float NdotL = max0(dot3(N, L));
+        f3 c = mk3(0.0f, 0.0f, 0.0f);
+        if (NdotL > 0.0f) c = texcube_rgb_linear(env, env_n, L);  // the shader's mip level is clamped to 0 by the sampler
+        term[0][s] = c.x; term[1][s] = c.y; term[2][s] = c.z; term[3][s] = NdotL;
     }
-    float iw = rcp_rn(total);
-    out[(size_t)row * n + i] = pack4(cr * iw, cg * iw, cb * iw, 1.0f);
+    __syncthreads();
+    if (tid < 4) {
+        const float4 *mine = (const float4 *)term[tid], *wts = (const float4 *)term[3];
+        float acc = 0.0f;
+        for (int q = 0; q < SAMPLE_COUNT / 4; q++) {
+            float4 c = mine[q];
+            const float4 wt = wts[q];
+            if (tid == 3) c = make_float4(1.0f, 1.0f, 1.0f, 1.0f);  // totalWeight += NdotL
+            // A sample the shader skips (N.L <= 0) was stored as colour 0, weight 0: adding
+            // 0 * 0 leaves the running sum's bits unchanged, so no test is needed here.
+            acc = fma_(c.x, wt.x, acc);
+            acc = fma_(c.y, wt.y, acc);
+            acc = fma_(c.z, wt.z, acc);
+            acc = fma_(c.w, wt.w, acc);
+        }
+        result[tid] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const float iw = rcp_rn(result[3]);
+        out[(size_t)row * n + i] = pack4(result[0] * iw, result[1] * iw, result[2] * iw, 1.0f);
+    }
 }
 
 // brdf.frag:81-119, one lane per texel; a workgroup works on one row (one roughness).
@@ -309,8 +348,8 @@ extern "C" int32_t vkr_ibl_irradiance(const void *env, int32_t env_n, void *out,
         dim3 grid(n, row_end - row_begin);
         hipLaunchKernelGGL(irradiance_slices_kernel, grid, dim3(256), 0, as_stream(stream), env, env_n, (uint2 *)out, n, g_irr_nphi, g_irr_ntheta, row_begin);
     } else {
-        dim3 grid((n + 63) / 64, row_end - row_begin);
-        hipLaunchKernelGGL(irradiance_kernel, grid, dim3(64), 0, as_stream(stream), env, env_n, (uint2 *)out, n, order, g_irr_nphi, g_irr_ntheta, row_begin, row_end);
+        dim3 grid(n, row_end - row_begin);
+        hipLaunchKernelGGL(irradiance_texel_kernel, grid, dim3(256), 0, as_stream(stream), env, env_n, (uint2 *)out, n, g_irr_nphi, g_irr_ntheta, row_begin);
     }
     return launch_status("vkr_ibl_irradiance");
 }
@@ -324,8 +363,8 @@ extern "C" int32_t vkr_ibl_prefilter(const void *env, int32_t env_n, void *out, 
     if (rc != VKR_OK) return rc;
     if ((rc = ensure_tables()) != VKR_OK) return rc;
     if (row_end == row_begin) return VKR_OK;
-    dim3 grid((n + 63) / 64, row_end - row_begin);
-    hipLaunchKernelGGL(prefilter_kernel, grid, dim3(64), 0, as_stream(stream), env, env_n, (uint2 *)out, n, roughness, row_begin, row_end);
+    dim3 grid(n, row_end - row_begin);
+    hipLaunchKernelGGL(prefilter_texel_kernel, grid, dim3(256), 0, as_stream(stream), env, env_n, (uint2 *)out, n, roughness, row_begin);
     return launch_status("vkr_ibl_prefilter");
 }
 
