@@ -91,6 +91,22 @@ def time_ibl(device) -> dict:
             "config": "equirect 4096x2048 RGBA16F -> env 2048^2, irradiance 64^2, prefilter 128^2 x5 mips, LUT 512^2"}
 
 
+def measured_traffic(lights: int, cube_res: int, dir_res: int) -> dict:
+    """HBM-side bytes per launch from the committed rocprofv3 counter passes (profiles/r1_traffic.json);
+    counters cannot be read from inside this process, so the figures apply only to the workload they
+    were collected on and are dropped (null) for any other."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_traffic.json")
+    try:
+        with open(path) as fh:
+            rec = json.load(fh)
+    except OSError:
+        return {}
+    w = rec.get("workload", {})
+    if (w.get("width"), w.get("rows"), w.get("lights"), w.get("cube_res"), w.get("dir_res")) != (WIDTH, HEIGHT, lights, cube_res, dir_res):
+        return {}
+    return {k: v["traffic_bytes"] for k, v in rec.get("kernels", {}).items()}
+
+
 def cpu_baseline(f, gpu_color, gpu_thr, sample_rows: int) -> dict:
     """The oracle (CPU restatement, OpenMP) on the first `sample_rows` rows of the same frame; also
     checks the GPU's rows against it bit for bit."""
@@ -196,6 +212,7 @@ def main() -> None:
     shaded_px = int((f.normal.view(np.float16)[..., :3] != 0).any(axis=-1).sum())
     flops = (OPS_PER_PIXEL + OPS_PER_PIXEL_LIGHT * args.lights) * shaded_px
     shade_tflops = flops / (kernel_ms["shade"] * 1e-3) / 1e12
+    traffic = measured_traffic(args.lights, args.cube_res, args.dir_res)
     out = {
         "metric": "Mpixels/s deferred PBR+bloom+ACES @4K 64 shadowed lights",
         "value": round(px * world / (elapsed / args.steps) / 1e6, 3),
@@ -208,17 +225,17 @@ def main() -> None:
                                f"{args.cube_res}^2 cube shadow maps + {args.dir_res}^2 directional PCF shadow; composition + bloom x2 + ACES/gamma",
                    "parallelism": f"strips{world}", "storage": "RGBA16F targets, RGBA8 output"},
         "roofline": {"bound": "valu", "kernel": "shade_kernel", "achieved": round(shade_tflops, 3), "peak": PEAK_FP32_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(shade_tflops / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                     "unit": "TFLOP/s", "frac": round(shade_tflops / PEAK_FP32_TFLOPS, 4), "traffic": traffic.get("shade_kernel"),
                      "algorithmic": f"({OPS_PER_PIXEL} + {OPS_PER_PIXEL_LIGHT} x {args.lights}) FP32 ops x {shaded_px} shaded pixels per launch "
                                     f"({px - shaded_px} background pixels of the {px} do no shading work)",
                      "avg_launch_ms": round(kernel_ms["shade"], 4)},
         "roofline_post": [
             {"bound": "hbm", "kernel": "bloom_h_kernel", "achieved": round(16 * px / (kernel_ms["bloom_h"] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
              "unit": "GB/s", "frac": round(16 * px / (kernel_ms["bloom_h"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "avg_launch_ms": round(kernel_ms["bloom_h"], 4),
-             "algorithmic": "16 B/pixel"},
+             "algorithmic": "16 B/pixel", "traffic": traffic.get("bloom_h_kernel")},
             {"bound": "hbm", "kernel": "bloom_v_kernel<fused post>", "achieved": round(20 * px / (kernel_ms["bloomv_post"] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
              "unit": "GB/s", "frac": round(20 * px / (kernel_ms["bloomv_post"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "avg_launch_ms": round(kernel_ms["bloomv_post"], 4),
-             "algorithmic": "20 B/pixel (8 bloom-1 + 8 colour in, 4 RGBA8 out)"}],
+             "algorithmic": "20 B/pixel (8 bloom-1 + 8 colour in, 4 RGBA8 out)", "traffic": traffic.get("bloom_v_kernel")}],
     }
     if not args.no_ibl:
         out["ibl_precompute"] = time_ibl(device)

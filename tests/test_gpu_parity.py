@@ -234,3 +234,58 @@ def test_renderer_end_frame_matches_oracle_chain(gpu, oracle):
         r.BeginFrame()
         with pytest.raises(_lib.VkrError):
             r.BeginFrame()
+
+
+def test_strip_pair_with_local_halo_copy_matches_whole_frame(gpu, oracle):
+    """Two strips of one frame rendered by two StripRenderers on one GPU, the halo rows copied
+    between them where the ranks of a real run would send them: exercises the split launches
+    (interior rows first, rows next to a neighbour afterwards) of the multi-GPU path."""
+    torch = _torch()
+    from vulkanrenderer_amd.strips import HALO, StripPlan, StripRenderer
+    P = _passes()
+    w, h, world = 200, 45, 2
+    f = synth.make_frame(41, w, h, 3, 32, 128, irr_res=8, pref_res=16, lut_res=32)
+    want = oracle.frame_chain(f)
+
+    class Paired(StripRenderer):
+        peers = None
+
+        def start_halo_exchange(self):
+            p, r = self.plan, self.plan.rows
+            if not p.is_top:
+                up = self.peers[p.rank - 1]
+                self.bloom1[0:HALO] = up.bloom1[up.plan.rows:up.plan.rows + HALO]
+            if not p.is_bottom:
+                self.bloom1[r + HALO:r + 2 * HALO] = self.peers[p.rank + 1].bloom1[HALO:2 * HALO]
+            return []
+
+    plans = [StripPlan.make(k, world, h) for k in range(world)]
+    frames = [P.DeviceFrame.upload(f.rows(p.row0, p.row0 + p.rows), gpu) for p in plans]
+    rs = [Paired(p, w, device=gpu) for p in plans]
+    for r in rs:
+        r.peers = rs
+    for r, d in zip(rs, frames):  # pass-1 images first: a strip reads its neighbour's boundary rows
+        r.backend.shade(d, r.color, r.threshold)
+        r.backend.bloom_h(r.threshold, r.bloom1, r.plan.rows)
+    ldr = torch.cat([r.render(d) for r, d in zip(rs, frames)], 0).cpu().numpy()
+    color = np.concatenate([P.f16_bits(r.color) for r in rs], 0)
+    assert_bits_equal(color, want["color"], "colour of the two strips")
+    assert np.abs(ldr.astype(np.int32) - want["ldr"].astype(np.int32)).max() <= 1
+    # and the split launches give the very bytes of a single launch over the whole frame
+    whole = StripRenderer(StripPlan.make(0, 1, h), w, device=gpu)
+    assert np.array_equal(whole.render(P.DeviceFrame.upload(f, gpu)).cpu().numpy(), ldr)
+
+
+def test_ibl_precompute_matches_oracle_at_cube_edges_and_corners(gpu, oracle):
+    """The whole precompute through vulkanrenderer_amd.ibl on sizes where most irradiance and
+    prefilter samples cross face edges and some hit cube corners (64^2 environment)."""
+    torch, P = _torch(), _passes()
+    from vulkanrenderer_amd.ibl import IblConfig, IblPrecompute
+    cfg = IblConfig(env_res=64, irradiance_res=8, prefilter_res=16, prefilter_mips=5, lut_res=48)
+    src = synth.make_equirect(np.random.default_rng(21), 256, 128, hdr=True)
+    res = IblPrecompute(cfg, device=gpu).run(P.to_device_f16(src, gpu), _lib.SRC_RGBA16F)
+    env = P.f16_bits(res["env"])  # the GPU's environment cube feeds both sides from here on
+    assert_bits_equal(P.f16_bits(res["irradiance"]), oracle.irradiance(env, 8, 0), "irradiance")
+    for m, cube in enumerate(res["prefilter"]):
+        assert_bits_equal(P.f16_bits(cube), oracle.prefilter(env, 16 >> m, m / 4.0), f"prefilter mip {m}")
+    assert_bits_equal(P.f16_bits(res["brdf_lut"]), oracle.brdf_lut(48), "BRDF LUT")

@@ -39,15 +39,15 @@ class OracleBackend:
         from tests import oracle
         self._bits(bloom1)[HALO:HALO + rows] = oracle.bloom_blur(self._bits(thr), True, oracle.WRAP_REPEAT)
 
-    def bloomv_post(self, bloom1, hdr, out, lo, hi):
+    def bloomv_post(self, bloom1, hdr, out, lo, hi, row0=0):
         from tests import oracle
         b = self._bits(bloom1)
         rows = hdr.shape[0]
-        # vertical blur of output row r centred on source row r + HALO, taps clamped to [lo, hi]
-        idx = np.clip(np.arange(-4, rows + 4) + HALO, lo, hi)
+        # vertical blur of output row k centred on source row k + row0 + HALO, taps clamped to [lo, hi]
+        idx = np.clip(np.arange(-4, rows + 4) + HALO + row0, lo, hi)
         padded = np.ascontiguousarray(b[idx])                       # rows + 8 rows, edges already clamped
         b2 = oracle.bloom_blur(padded, False, oracle.WRAP_CLAMP)[4:4 + rows]
-        out.numpy()[...] = oracle.postprocess(self._bits(hdr), np.ascontiguousarray(b2))
+        out.numpy()[...] = oracle.postprocess(np.ascontiguousarray(self._bits(hdr)), np.ascontiguousarray(b2))
 
 
 def _frame():

@@ -1,0 +1,109 @@
+"""IBL precompute split over GPUs (one process per GPU).
+
+The reference runs the four precompute steps once, on one device, in its constructor
+(VulkanRenderer.cs:271-275: CreateSkyboxCubemap, CreateIrradianceCubemap, CreatePrefilteredCubemap,
+CreateBRDFLUTTexture).  Every output texel is independent, so the work splits by rows: the
+environment cube is resampled redundantly on every rank (cheaper than moving 201 MB), then each
+rank computes an equal slice of the rows of the irradiance cube, of every prefilter mip and of the
+BRDF LUT, and the slices are all-gathered (every rank needs the full images for shading).  Each
+mip is split on its own, so the per-rank cost is equal although mip 0 holds 75 % of the texels.
+No arithmetic crosses a rank boundary: the gathered images are bit-identical to a one-GPU run.
+"""
+from __future__ import annotations
+
+import dataclasses
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+@dataclasses.dataclass(frozen=True)
+class IblConfig:
+    env_res: int = 512          # VulkanRenderer.cs:653 (skybox cube)
+    irradiance_res: int = 32    # VulkanRenderer.cs:734
+    prefilter_res: int = 128    # VulkanRenderer.cs:815
+    prefilter_mips: int = 5     # roughness = mip / (mips - 1), VulkanRenderer.cs:874
+    lut_res: int = 512          # VulkanRenderer.cs:966
+
+
+def row_share(total_rows: int, rank: int, world: int) -> tuple[int, int, int]:
+    """(row_begin, row_end, rows_per_rank): equal chunks of ceil(total/world) rows, the last ones short or empty."""
+    per = -(-total_rows // world)
+    return min(rank * per, total_rows), min((rank + 1) * per, total_rows), per
+
+
+class HipIblBackend:
+    """The product backend: libvkr_hip.so kernels on torch CUDA tensors."""
+
+    def __init__(self, device):
+        from . import passes
+        _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("the IBL precompute needs a GPU: there is no CPU path")
+        self.P = passes
+        self.device = device
+
+    def empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def equirect(self, src, src_format, env):
+        self.P.equirect_to_cube(src, src_format, env)
+
+    def irradiance(self, env, out, rows):
+        self.P.irradiance(env, out, _lib.IRRADIANCE_SEQUENTIAL, rows=rows)
+
+    def prefilter(self, env, out, roughness, rows):
+        self.P.prefilter(env, out, roughness, rows=rows)
+
+    def brdf_lut(self, out, rows):
+        self.P.brdf_lut(out, rows=rows)
+
+
+class IblPrecompute:
+    """Computes this rank's rows of every IBL image and all-gathers them."""
+
+    def __init__(self, cfg: IblConfig, rank: int = 0, world: int = 1, device=None, backend=None, group=None):
+        self.cfg, self.rank, self.world, self.group = cfg, rank, world, group
+        self.backend = backend if backend is not None else HipIblBackend(device)
+
+    def _padded_cube(self, n: int):
+        """A cube image whose 6n rows are padded to a multiple of the world size: (flat rows view, cube view)."""
+        _, _, per = row_share(6 * n, self.rank, self.world)
+        flat = self.backend.empty((per * self.world, n, 4), torch.float16)
+        return flat, flat[:6 * n].view(6, n, n, 4)
+
+    def _all_gather_rows(self, flat: torch.Tensor, per: int) -> None:
+        if self.world == 1:
+            return
+        mine = flat[self.rank * per:(self.rank + 1) * per]
+        dist.all_gather_into_tensor(flat, mine, group=self.group)
+
+    def run(self, src: torch.Tensor, src_format: int) -> dict:
+        cfg, be = self.cfg, self.backend
+        env = be.empty((6, cfg.env_res, cfg.env_res, 4), torch.float16)
+        be.equirect(src, src_format, env)  # replicated
+
+        n = cfg.irradiance_res
+        irr_flat, irr = self._padded_cube(n)
+        r0, r1, per = row_share(6 * n, self.rank, self.world)
+        be.irradiance(env, irr, (r0, r1))
+        self._all_gather_rows(irr_flat, per)
+
+        mips = []
+        for m in range(cfg.prefilter_mips):
+            n = cfg.prefilter_res >> m
+            flat, cube = self._padded_cube(n)
+            r0, r1, per = row_share(6 * n, self.rank, self.world)
+            be.prefilter(env, cube, m / max(cfg.prefilter_mips - 1, 1), (r0, r1))
+            self._all_gather_rows(flat, per)
+            mips.append(cube)
+
+        n = cfg.lut_res
+        r0, r1, per = row_share(n, self.rank, self.world)
+        lut_flat = be.empty((per * self.world, n, 2), torch.float16)
+        lut = lut_flat[:n]
+        be.brdf_lut(lut, (r0, r1))
+        self._all_gather_rows(lut_flat, per)
+        return {"env": env, "irradiance": irr, "prefilter": mips, "brdf_lut": lut}

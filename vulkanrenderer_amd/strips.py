@@ -70,8 +70,9 @@ class HipBackend:
         # writes rows [HALO, HALO + rows) of the halo-padded pass-1 image
         self.P.bloom_blur(thr, bloom1[HALO:HALO + rows], True, _lib.WRAP_REPEAT, rows=rows)
 
-    def bloomv_post(self, bloom1, hdr, out, lo, hi):
-        self.P.bloomv_postprocess(bloom1, hdr, out, 0, src_row_offset=HALO, clamp_lo=lo, clamp_hi=hi)
+    def bloomv_post(self, bloom1, hdr, out, lo, hi, row0=0):
+        # output row k of `hdr`/`out` is strip row row0 + k, centred on row HALO + row0 + k of bloom1
+        self.P.bloomv_postprocess(bloom1, hdr, out, 0, src_row_offset=HALO + row0, clamp_lo=lo, clamp_hi=hi)
 
 
 class StripRenderer:
@@ -87,11 +88,12 @@ class StripRenderer:
         self.ldr = self.backend.empty((r, width, 4), torch.uint8)
         self._gathered = None  # receive buffers of gather(), allocated on first use
 
-    def exchange_halo(self) -> None:
-        """Rows HALO..2*HALO go to the rank above, the last HALO real rows to the rank below."""
+    def start_halo_exchange(self) -> list:
+        """Rows HALO..2*HALO go to the rank above, the last HALO real rows to the rank below.
+        Returns the pending requests (empty on a single rank)."""
         p, r = self.plan, self.plan.rows
         if p.world == 1:
-            return
+            return []
         ops = []
         if not p.is_top:
             ops.append(dist.P2POp(dist.isend, self.bloom1[HALO:2 * HALO], p.rank - 1, self.group))
@@ -99,19 +101,34 @@ class StripRenderer:
         if not p.is_bottom:
             ops.append(dist.P2POp(dist.isend, self.bloom1[r:r + HALO], p.rank + 1, self.group))
             ops.append(dist.P2POp(dist.irecv, self.bloom1[r + HALO:r + 2 * HALO], p.rank + 1, self.group))
-        for req in dist.batch_isend_irecv(ops):
+        return dist.batch_isend_irecv(ops)
+
+    def exchange_halo(self) -> None:
+        for req in self.start_halo_exchange():
             req.wait()
 
     def render(self, frame) -> torch.Tensor:
-        """composition -> bloom 1 -> halo exchange -> bloom 2 + post-process; returns the RGBA8 strip."""
+        """composition -> bloom 1 -> halo exchange overlapped with the interior rows of bloom 2 +
+        post-process -> the rows next to a neighbour; returns the RGBA8 strip."""
         p, r = self.plan, self.plan.rows
-        self.backend.shade(frame, self.color, self.threshold)
-        self.backend.bloom_h(self.threshold, self.bloom1, r)
-        self.exchange_halo()
+        be = self.backend
+        be.shade(frame, self.color, self.threshold)
+        be.bloom_h(self.threshold, self.bloom1, r)
         # frame edges clamp (CLAMP_TO_EDGE); interior strip edges read the neighbours' rows
         lo = HALO if p.is_top else 0
         hi = HALO + r - 1 if p.is_bottom else r + 2 * HALO - 1
-        self.backend.bloomv_post(self.bloom1, self.color, self.ldr, lo, hi)
+        # rows [top, bottom) reach no halo row: they run while the halo rows are in flight
+        top = 0 if p.is_top else HALO
+        bottom = r if p.is_bottom else r - HALO
+        pending = self.start_halo_exchange()
+        if bottom > top:
+            be.bloomv_post(self.bloom1, self.color[top:bottom], self.ldr[top:bottom], lo, hi, row0=top)
+        for req in pending:
+            req.wait()
+        if top > 0:
+            be.bloomv_post(self.bloom1, self.color[:top], self.ldr[:top], lo, hi, row0=0)
+        if bottom < r:
+            be.bloomv_post(self.bloom1, self.color[max(bottom, top):], self.ldr[max(bottom, top):], lo, hi, row0=max(bottom, top))
         return self.ldr
 
     def gather(self, dst: int = 0):
