@@ -77,7 +77,7 @@ public sealed unsafe class HipRenderer : IDisposable
     public void UploadPointShadowMap(int light, float* depthCube) => Check(Native.vkr_upload_point_shadow(ctx, light, depthCube));
 
     public void CreateSkyboxCubemap(void* equirect, int w, int h, int format) => Check(Native.vkr_create_skybox_cubemap(ctx, equirect, w, h, format));
-    public void CreateIrradianceCubemap() => Check(Native.vkr_create_irradiance_cubemap(ctx, 1));
+    public void CreateIrradianceCubemap() => Check(Native.vkr_create_irradiance_cubemap(ctx, 0));
     public void CreatePrefilteredCubemap() => Check(Native.vkr_create_prefiltered_cubemap(ctx));
     public void CreateBRDFLUTTexture() => Check(Native.vkr_create_brdf_lut(ctx));
 

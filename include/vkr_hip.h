@@ -78,7 +78,7 @@ typedef struct VkrLightInfo {
 #define VKR_POST_SRGB_TARGET 1 /* store through an _SRGB target format (SCDevice.cs:655-666) */
 
 #define VKR_IRRADIANCE_SEQUENTIAL 0 /* one running sum, the shader's own order */
-#define VKR_IRRADIANCE_PHI_SLICES 1 /* per-phi partial sums added in phi order (faster) */
+#define VKR_IRRADIANCE_PHI_SLICES 1 /* every phi slice summed from zero, slice sums added in phi order */
 
 VKR_EXPORT const char *vkr_last_error(void);
 VKR_EXPORT int32_t vkr_abi_version(void);

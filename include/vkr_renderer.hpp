@@ -97,7 +97,7 @@ public:
     // IBL precompute (VulkanRenderer.cs:271-275)
     void CreateSkyboxCubemap(const void *equirect, int32_t w, int32_t h, int32_t format) { check(vkr_create_skybox_cubemap(ctx_, equirect, w, h, format)); }
     void UploadEnvironmentCubemap(const void *cube) { check(vkr_upload_env_cube(ctx_, cube)); }
-    void CreateIrradianceCubemap(int32_t order = VKR_IRRADIANCE_PHI_SLICES) { check(vkr_create_irradiance_cubemap(ctx_, order)); }
+    void CreateIrradianceCubemap(int32_t order = VKR_IRRADIANCE_SEQUENTIAL) { check(vkr_create_irradiance_cubemap(ctx_, order)); }
     void CreatePrefilteredCubemap() { check(vkr_create_prefiltered_cubemap(ctx_)); }
     void CreateBRDFLUTTexture() { check(vkr_create_brdf_lut(ctx_)); }
 

@@ -289,3 +289,42 @@ def test_ibl_precompute_matches_oracle_at_cube_edges_and_corners(gpu, oracle):
     for m, cube in enumerate(res["prefilter"]):
         assert_bits_equal(P.f16_bits(cube), oracle.prefilter(env, 16 >> m, m / 4.0), f"prefilter mip {m}")
     assert_bits_equal(P.f16_bits(res["brdf_lut"]), oracle.brdf_lut(48), "BRDF LUT")
+
+
+def test_cpp_host_program_matches_oracle(gpu, oracle, tmp_path):
+    """tests/cpp/renderer_roundtrip (built by __graft_entry__.build()) drives vkr::HipRenderer from
+    C++ the way the reference's render loop drives VulkanRenderer; its frame equals the oracle's."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "renderer_roundtrip")
+    assert os.path.exists(exe), "tests/cpp/renderer_roundtrip is not built: run __graft_entry__.build()"
+    w, h, nl, dres, cres, eres, ires, pres, lres = 104, 56, 3, 64, 16, 16, 4, 8, 16
+    f = synth.make_frame(52, w, h, nl, cres, dres, irr_res=ires, pref_res=pres, lut_res=lres)
+    env = synth.make_env_cube(np.random.default_rng(8), eres)
+    inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(inp, "wb") as fh:
+        fh.write(np.array([w, h, nl, dres, cres, eres, ires, pres, lres], dtype=np.int32).tobytes())
+        fh.write(f.scene.tobytes())
+        for l in f.lights:
+            fh.write(np.asarray(l["position"][:3], dtype=np.float32).tobytes())
+            fh.write(np.asarray(l["color"][:3], dtype=np.float32).tobytes())
+        for a in (f.albedo, f.normal, f.arm, f.position, f.dir_shadow, f.cube_shadow, env):
+            fh.write(np.ascontiguousarray(a).tobytes())
+    proc = subprocess.run([exe, str(inp), str(outp)], capture_output=True, text=True, timeout=100)
+    assert proc.returncode == 0, proc.stderr
+    raw = np.fromfile(outp, dtype=np.uint8)
+    sizes = [w * h * 8, w * h * 8, w * h * 4, 6 * ires * ires * 8, 6 * pres * pres * 8, lres * lres * 4]
+    assert raw.size == sum(sizes)
+    parts = np.split(raw, np.cumsum(sizes)[:-1])
+    color, thr = (p.view(np.uint16).reshape(h, w, 4) for p in parts[:2])
+    ldr = parts[2].reshape(h, w, 4)
+    f.irradiance = parts[3].view(np.uint16).reshape(6, ires, ires, 4)
+    f.prefilter = parts[4].view(np.uint16).reshape(6, pres, pres, 4)
+    f.brdf_lut = parts[5].view(np.uint16).reshape(lres, lres, 2)
+    assert_bits_equal(f.irradiance, oracle.irradiance(env, ires, 0), "irradiance")
+    assert_bits_equal(f.prefilter, oracle.prefilter(env, pres, 0.0), "prefilter")
+    assert_bits_equal(f.brdf_lut, oracle.brdf_lut(lres), "BRDF LUT")
+    want = oracle.frame_chain(f)
+    assert_bits_equal(color, want["color"], "colour")
+    assert_bits_equal(thr, want["threshold"], "threshold")
+    assert np.abs(ldr.astype(np.int32) - want["ldr"].astype(np.int32)).max() <= 1

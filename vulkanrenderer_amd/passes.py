@@ -141,7 +141,7 @@ def equirect_to_cube(src: torch.Tensor, src_format: int, cube: torch.Tensor, row
     _lib.check(lib.vkr_ibl_equirect_to_cube(_ptr(src), src.shape[1], src.shape[0], src_format, _ptr(cube), n, r0, r1, _stream()))
 
 
-def irradiance(env: torch.Tensor, out: torch.Tensor, order: int = _lib.IRRADIANCE_PHI_SLICES, rows=None) -> None:
+def irradiance(env: torch.Tensor, out: torch.Tensor, order: int = _lib.IRRADIANCE_SEQUENTIAL, rows=None) -> None:
     lib = _lib.load()
     n = out.shape[1]
     r0, r1 = _rows(6 * n, rows)

@@ -171,7 +171,7 @@ class HipRenderer:
         assert a.dtype == np.uint16 and a.shape == (6, self.env_res, self.env_res, 4)
         self._call(self._lib.vkr_upload_env_cube, _host_ptr(a))
 
-    def CreateIrradianceCubemap(self, order: int = _lib.IRRADIANCE_PHI_SLICES) -> None:
+    def CreateIrradianceCubemap(self, order: int = _lib.IRRADIANCE_SEQUENTIAL) -> None:
         self._call(self._lib.vkr_create_irradiance_cubemap, order)
 
     def CreatePrefilteredCubemap(self) -> None:
