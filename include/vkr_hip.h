@@ -69,6 +69,12 @@ typedef struct VkrLightInfo {
  * whenever the camera is inside every light volume. */
 #define VKR_COVERAGE_FULLSCREEN 0
 
+/* Memory layout of the D32F point-shadow cubes (the reference keeps them in OPTIMAL-tiled Vulkan
+ * images, VulkanRenderer.cs:1348-1370, whose layout is the driver's; here it is explicit). */
+#define VKR_CUBE_LAYOUT_LINEAR 0    /* [light][face][row][column], tight */
+#define VKR_CUBE_LAYOUT_TILED_8X4 1 /* each face as row-major 8x4-texel tiles of 128 bytes; face size % 8 == 0;
+                                       made from the linear layout by vkr_tile_depth_cubes() */
+
 #define VKR_WRAP_REPEAT 0 /* textureSampler, VulkanHelper.cs:123-154 */
 #define VKR_WRAP_CLAMP 1  /* bloomSampler,   VulkanHelper.cs:156-187 */
 
@@ -102,12 +108,18 @@ typedef struct VkrShadeArgs {
     int32_t coverage_mode;
     const float *dir_shadow;  int32_t dir_res;    /* D32F dir_res^2 */
     const float *cube_shadow; int32_t cube_res;   /* D32F n_lights * 6 * cube_res^2 */
+    int32_t cube_layout;                          /* VKR_CUBE_LAYOUT_* of cube_shadow */
     const void *irradiance;   int32_t irr_res;    /* RGBA16F cube */
     const void *prefilter;    int32_t pref_res;   /* RGBA16F cube (mip 0) */
     const void *brdf_lut;     int32_t lut_res;    /* RG16F */
     void *out_color, *out_threshold;              /* RGBA16F, rows*width texels each */
 } VkrShadeArgs;
 VKR_EXPORT int32_t vkr_shade(const VkrShadeArgs *args, void *stream);
+
+/* Re-lays `n_faces` D32F faces of `res`^2 texels from VKR_CUBE_LAYOUT_LINEAR to
+ * VKR_CUBE_LAYOUT_TILED_8X4 (res % 8 == 0; src and dst must not overlap).  No counterpart in the
+ * reference, whose depth images are written tiled by the rasteriser. */
+VKR_EXPORT int32_t vkr_tile_depth_cubes(const float *linear, float *tiled, int32_t n_faces, int32_t res, void *stream);
 
 /* Replaces one bloom_blur.frag draw (VulkanRenderer.cs:504-540).  Writes `rows` output rows;
  * output row r is centred on source row r + src_row_offset.  Taps along the blur axis wrap

@@ -328,3 +328,47 @@ def test_cpp_host_program_matches_oracle(gpu, oracle, tmp_path):
     assert_bits_equal(color, want["color"], "colour")
     assert_bits_equal(thr, want["threshold"], "threshold")
     assert np.abs(ldr.astype(np.int32) - want["ldr"].astype(np.int32)).max() <= 1
+
+
+@pytest.mark.parametrize("seed,w,h,nl,cube,dres", FRAMES)
+def test_shade_bit_exact_with_row_major_cubes(gpu, oracle, seed, w, h, nl, cube, dres):
+    """The same frames with the point-shadow cubes left row-major (test_shade_bit_exact uses 8x4 tiles)."""
+    torch, P = _torch(), _passes()
+    f = synth.make_frame(seed, w, h, nl, cube, dres, irr_res=8, pref_res=16, lut_res=32)
+    want_c, want_t = oracle.shade(f)
+    d = P.DeviceFrame.upload(f, gpu, tiled=False)
+    assert d.cube_layout == _lib.CUBE_LAYOUT_LINEAR
+    color = torch.empty((h, w, 4), dtype=torch.float16, device=gpu)
+    thr = torch.empty_like(color)
+    P.shade(d, color, thr)
+    assert_bits_equal(P.f16_bits(color), want_c, "composition colour")
+    assert_bits_equal(P.f16_bits(thr), want_t, "thresholded colour")
+
+
+def test_tiled_cube_layout(gpu, oracle):
+    """vkr_tile_depth_cubes against the layout's definition; a face size that is not a multiple of 8
+    stays row-major and is refused for the tiled layout."""
+    torch, P = _torch(), _passes()
+    res = 24
+    lin = torch.arange(2 * 6 * res * res, dtype=torch.float32, device=gpu).reshape(2, 6, res, res)
+    got = P.tile_depth_cubes(lin).cpu().numpy().reshape(12, -1)
+    src = lin.cpu().numpy().reshape(12, res, res)
+    j, i = np.meshgrid(np.arange(res), np.arange(res), indexing="ij")
+    index = ((j >> 2) * (res >> 3) + (i >> 3)) * 32 + (j & 3) * 8 + (i & 7)
+    want = np.empty_like(got)
+    want[:, index.ravel()] = src.reshape(12, -1)
+    assert np.array_equal(got, want)
+
+    f = synth.make_frame(15, 72, 40, 2, 12, 64, irr_res=8, pref_res=16, lut_res=32)  # 12^2 faces
+    d = P.DeviceFrame.upload(f, gpu)
+    assert d.cube_layout == _lib.CUBE_LAYOUT_LINEAR
+    color = torch.empty((40, 72, 4), dtype=torch.float16, device=gpu)
+    thr = torch.empty_like(color)
+    P.shade(d, color, thr)
+    want_c, want_t = oracle.shade(f)
+    assert_bits_equal(P.f16_bits(color), want_c, "composition colour, 12^2 cube faces")
+    d.cube_layout = _lib.CUBE_LAYOUT_TILED_8X4
+    with pytest.raises(_lib.VkrError):
+        P.shade(d, color, thr)
+    with pytest.raises(_lib.VkrError):
+        P.tile_depth_cubes(d.cube_shadow)

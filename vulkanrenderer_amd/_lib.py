@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("VKR_HIP_LIB") or os.path.join(_HERE, "libvkr_hip.so")
 VKR_OK = 0
 VKR_ERR_INVALID, VKR_ERR_HIP, VKR_ERR_UNSUPPORTED, VKR_ERR_ORDER, VKR_ERR_NO_DEVICE = -1, -2, -3, -4, -5
 COVERAGE_FULLSCREEN = 0
+CUBE_LAYOUT_LINEAR, CUBE_LAYOUT_TILED_8X4 = 0, 1
 WRAP_REPEAT, WRAP_CLAMP = 0, 1
 SRC_RGBA8_SRGB, SRC_RGBA16F = 0, 1
 POST_SRGB_TARGET = 1
@@ -52,7 +53,7 @@ class ShadeArgs(C.Structure):
                 ("scene", SceneInfo),
                 ("lights", C.c_void_p), ("n_lights", C.c_int32), ("coverage_mode", C.c_int32),
                 ("dir_shadow", C.c_void_p), ("dir_res", C.c_int32),
-                ("cube_shadow", C.c_void_p), ("cube_res", C.c_int32),
+                ("cube_shadow", C.c_void_p), ("cube_res", C.c_int32), ("cube_layout", C.c_int32),
                 ("irradiance", C.c_void_p), ("irr_res", C.c_int32),
                 ("prefilter", C.c_void_p), ("pref_res", C.c_int32),
                 ("brdf_lut", C.c_void_p), ("lut_res", C.c_int32),
@@ -89,6 +90,7 @@ PROTOTYPES = {
     "vkr_abi_version": [],
     "vkr_device_count": [],
     "vkr_shade": [C.POINTER(ShadeArgs), _vp],
+    "vkr_tile_depth_cubes": [_vp, _vp, C.c_int32, C.c_int32, _vp],
     "vkr_bloom_blur": [C.POINTER(BloomArgs), _vp],
     "vkr_postprocess": [_vp, _vp, _vp, _i32, _i32, _i32, _vp],
     "vkr_bloomv_postprocess": [C.POINTER(BloomPostArgs), _vp],

@@ -46,6 +46,8 @@ struct vkr_ctx {
     void *env = nullptr, *irradiance = nullptr, *brdf_lut = nullptr;
     std::vector<void *> prefilter;  // one image per mip
     bool have_env = false, have_irr = false, have_pref = false, have_lut = false;
+    float *cube_staging = nullptr;  // one linear depth cube on its way into the tiled storage
+    bool cubes_tiled = false;       // point shadow cubes are stored VKR_CUBE_LAYOUT_TILED_8X4
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timing_valid = false;
 };
@@ -92,7 +94,7 @@ static void destroy(vkr_ctx *c)
         if (f.cube_shadow) (void)hipFree(f.cube_shadow);
         if (f.lights) (void)hipFree(f.lights);
     }
-    void *ibl[] = {c->env, c->irradiance, c->brdf_lut};
+    void *ibl[] = {c->env, c->irradiance, c->brdf_lut, c->cube_staging};
     for (void *p : ibl) if (p) (void)hipFree(p);
     for (void *p : c->prefilter) if (p) (void)hipFree(p);
     for (hipEvent_t e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -116,6 +118,7 @@ static int32_t fill_shade_args(vkr_ctx *c, Frame &f, VkrShadeArgs &a)
     a.lights = f.lights; a.n_lights = f.n_lights; a.coverage_mode = f.coverage;
     a.dir_shadow = f.dir_shadow; a.dir_res = c->cfg.dir_shadow_res;
     a.cube_shadow = f.cube_shadow; a.cube_res = c->cfg.point_shadow_res;
+    a.cube_layout = c->cubes_tiled ? VKR_CUBE_LAYOUT_TILED_8X4 : VKR_CUBE_LAYOUT_LINEAR;
     a.irradiance = c->irradiance; a.irr_res = c->cfg.irradiance_res;
     a.prefilter = c->prefilter[0]; a.pref_res = c->cfg.prefilter_res;
     a.brdf_lut = c->brdf_lut; a.lut_res = c->cfg.brdf_lut_res;
@@ -202,6 +205,8 @@ extern "C" int32_t vkr_create(const VkrConfig *config, vkr_ctx **out)
             VKR_HIP_CHECK(hipMalloc((void **)&f.cube_shadow, (size_t)cfg.max_lights * 6 * cfg.point_shadow_res * cfg.point_shadow_res * 4));
             VKR_HIP_CHECK(hipMalloc((void **)&f.lights, (size_t)cfg.max_lights * sizeof(VkrLightInfo)));
         }
+        c->cubes_tiled = cfg.point_shadow_res % 8 == 0;
+        if (c->cubes_tiled) VKR_HIP_CHECK(hipMalloc((void **)&c->cube_staging, (size_t)6 * cfg.point_shadow_res * cfg.point_shadow_res * 4));
         VKR_HIP_CHECK(hipMalloc(&c->env, cube_bytes(cfg.env_res)));
         VKR_HIP_CHECK(hipMalloc(&c->irradiance, cube_bytes(cfg.irradiance_res)));
         VKR_HIP_CHECK(hipMalloc(&c->brdf_lut, (size_t)cfg.brdf_lut_res * cfg.brdf_lut_res * 4));
@@ -311,7 +316,14 @@ extern "C" int32_t vkr_upload_point_shadow(vkr_ctx *c, int32_t light, const floa
     VKR_REQUIRE(depth_cube != nullptr, "vkr_upload_point_shadow: depth cube is null");
     VKR_REQUIRE(light >= 0 && light < c->cfg.max_lights, "vkr_upload_point_shadow: light %d outside [0,%d)", light, c->cfg.max_lights);
     size_t per = (size_t)6 * c->cfg.point_shadow_res * c->cfg.point_shadow_res;
-    return upload(c, c->frames[c->frame].cube_shadow + per * light, depth_cube, per * 4);
+    float *dst = c->frames[c->frame].cube_shadow + per * light;
+    if (!c->cubes_tiled) return upload(c, dst, depth_cube, per * 4);
+    // host rows -> staging -> 8x4-texel tiles (what the shade kernel's gathers are laid out for)
+    VKR_HIP_CHECK(hipMemcpyAsync(c->cube_staging, depth_cube, per * 4, hipMemcpyHostToDevice, c->stream));
+    int32_t rc = vkr_tile_depth_cubes(c->cube_staging, dst, 6, c->cfg.point_shadow_res, c->stream);
+    if (rc != VKR_OK) return rc;
+    VKR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return VKR_OK;
 }
 
 extern "C" int32_t vkr_create_skybox_cubemap(vkr_ctx *c, const void *equirect, int32_t w, int32_t h, int32_t src_format)

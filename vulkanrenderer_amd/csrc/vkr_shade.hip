@@ -4,9 +4,10 @@
 // binary16 after every light, exactly as the per-draw additive blend of
 // GraphicsPipelineBuilder.cs:157-187 does, then written once.
 //
-// Work layout: a 16x16-pixel workgroup of four wave64s, each wave an 8x8-pixel block, so the 64
-// lanes of a wave look up neighbouring shadow-map texels.  Light parameters are wave-uniform and
-// come in through scalar loads.  The 20 cube-shadow taps of light.frag:131-137 only ever combine
+// Work layout: one wave64 per workgroup, shading an 8x8-pixel block, so the 64 lanes of a wave look
+// up neighbouring shadow-map texels (one-wave workgroups measured 3 % faster than 16x16-pixel
+// groups of four waves, and 20 % faster than 32x32 groups of sixteen).  Light parameters are
+// wave-uniform and come in through scalar loads.  The 20 cube-shadow taps of light.frag:131-137 only ever combine
 // three x, three y and three z coordinates (v, v - r, v + r), so their face coordinates are
 // computed once per coordinate pair instead of once per tap; when every tap of every lane of the
 // wave falls on one cube face (the common case) the face selection disappears altogether.
@@ -111,11 +112,28 @@ VKR_DEV void lut_sample(const uint32_t *lut, int n, float s, float t, float &o0,
     o1 = fma_(w11, (float)p11.y, fma_(w01, (float)p01.y, fma_(w10, (float)p10.y, w00 * (float)p00.y)));
 }
 
+// Byte offset of texel (i, j) inside one face = col_bytes(i) + row_bytes(j).  Row-major:
+// 4i + 4*res*j.  Tiled (VKR_CUBE_LAYOUT_TILED_8X4): the face is cut into tiles of 8x4 texels,
+// one 128-byte cache line each, stored row-major by tile; inside a tile rows of 8 texels follow
+// each other.  A wave's 8x8-pixel footprint then touches about 40 % fewer lines.
+template <bool TILED> VKR_DEV unsigned col_bytes(int i)
+{
+    return TILED ? __umul24((unsigned)i >> 3, 96u) + (unsigned)i * 4u : (unsigned)i * 4u;  // (i>>3)*128 + (i&7)*4
+}
+template <bool TILED> VKR_DEV unsigned row_bytes(int j, unsigned res)
+{
+    // tiled: (j>>2) * (res/8 tiles * 128 B) + (j&3)*32
+    return TILED ? __umul24((unsigned)j >> 2, 16u * res - 128u) + (unsigned)j * 32u : __umul24((unsigned)j, res * 4u);
+}
+
 // light.frag:20-27, as indices into {v - r, v, v + r}
-#define VKR_GRID20(T)                                                                              \
+#define VKR_GRID20A(T)                                                                             \
     T(2, 2, 2) T(2, 0, 2) T(0, 0, 2) T(0, 2, 2) T(2, 2, 0) T(2, 0, 0) T(0, 0, 0) T(0, 2, 0)        \
-    T(2, 2, 1) T(2, 0, 1) T(0, 0, 1) T(0, 2, 1) T(2, 1, 2) T(0, 1, 2) T(2, 1, 0) T(0, 1, 0)        \
+    T(2, 2, 1) T(2, 0, 1)
+#define VKR_GRID20B(T)                                                                             \
+    T(0, 0, 1) T(0, 2, 1) T(2, 1, 2) T(0, 1, 2) T(2, 1, 0) T(0, 1, 0)        \
     T(1, 2, 2) T(1, 0, 2) T(1, 0, 0) T(1, 2, 0)
+#define VKR_GRID20(T) VKR_GRID20A(T) VKR_GRID20B(T)
 
 // Texel coordinate (already clamped, as a byte offset when scale = 4) of face coordinate c / ma
 VKR_DEV int face_texel(float c, float ima, float fres, int res)
@@ -132,7 +150,7 @@ VKR_DEV int face_texel(float c, float ima, float fres, int res)
 // the wave lies on cube face `face` (wave-uniform).  U, W are the coordinates that become sc, tc
 // (sign already applied), IM the reciprocals of |major coordinate|; the index triple of a tap is
 // permuted so that (iu, iw, im) index U, W, IM.
-template <int AXIS>
+template <int AXIS, bool TILED>
 VKR_DEV int taps_one_face(const float *face_base, int res, const float (&X)[3], const float (&Y)[3], const float (&Z)[3], bool neg, float cur)
 {
     const float fres = (float)res;
@@ -141,8 +159,7 @@ VKR_DEV int taps_one_face(const float *face_base, int res, const float (&X)[3], 
 #pragma unroll
     for (int k = 0; k < 3; k++) IM[k] = fast_rcp_rn(__builtin_fabsf(M[k]));
     // z major: sc = +-x, tc = -y;  y major: sc = x, tc = +-z;  x major: sc = -+z, tc = -y
-    int I[3][3], J[3][3];  // [index into U / W][index into M]
-    const int res4 = res * 4;
+    unsigned I[3][3], J[3][3];  // byte offsets of the column / row, [index into U / W][index into M]
 #pragma unroll
     for (int a = 0; a < 3; a++)
 #pragma unroll
@@ -152,68 +169,64 @@ VKR_DEV int taps_one_face(const float *face_base, int res, const float (&X)[3], 
             if (AXIS == 2) { u = neg ? -X[a] : X[a]; w = -Y[a]; }
             else if (AXIS == 1) { u = X[a]; w = neg ? -Z[a] : Z[a]; }
             else { u = neg ? Z[a] : -Z[a]; w = -Y[a]; }
-            I[a][m] = face_texel(u, IM[m], fres, res) * 4;
-            J[a][m] = face_texel(w, IM[m], fres, res);
+            I[a][m] = col_bytes<TILED>(face_texel(u, IM[m], fres, res));
+            J[a][m] = row_bytes<TILED>(face_texel(w, IM[m], fres, res), (unsigned)res);
         }
     int count = 0;
     const char *base = (const char *)face_base;
 #define VKR_TAP(gx, gy, gz)                                                              \
     {                                                                                    \
         constexpr int iu = AXIS == 0 ? gz : gx, iw = AXIS == 1 ? gz : gy, im = AXIS == 2 ? gz : (AXIS == 1 ? gy : gx); \
-        unsigned off = __umul24((unsigned)J[iw][im], (unsigned)res4) + (unsigned)I[iu][im]; \
+        unsigned off = J[iw][im] + I[iu][im];                                            \
         float closest = *(const float *)(base + off) * 25.0f;                            \
         count += cur > closest ? 1 : 0;                                                  \
     }
-    VKR_GRID20(VKR_TAP)
+    VKR_GRID20A(VKR_TAP)
+    asm volatile("" : "+v"(count));  // two batches of ten loads: fewer registers hold values in flight
+    VKR_GRID20B(VKR_TAP)
 #undef VKR_TAP
     return count;
 }
 
 // The same count with the cube face chosen per tap and per lane (light.frag:133 through
-// shadowSampler: NEAREST on the face the direction's major axis selects).
+// shadowSampler: NEAREST on the face the direction's major axis selects).  This path runs for
+// the few waves that straddle a face edge; it recomputes everything per tap so that it needs no
+// more registers than the one-face path, which sets the kernel's occupancy.
+template <bool TILED>
 VKR_DEV int taps_any_face(const float *cube, int res, const float (&X)[3], const float (&Y)[3], const float (&Z)[3], float cur)
 {
     const float fres = (float)res;
-    float AX[3], AY[3], AZ[3], IX[3], IY[3], IZ[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        AX[k] = __builtin_fabsf(X[k]); AY[k] = __builtin_fabsf(Y[k]); AZ[k] = __builtin_fabsf(Z[k]);
-        IX[k] = fast_rcp_rn(AX[k]); IY[k] = fast_rcp_rn(AY[k]); IZ[k] = fast_rcp_rn(AZ[k]);
-    }
-    const unsigned res4 = (unsigned)res * 4u;
+    const unsigned face_bytes = (unsigned)res * (unsigned)res * 4u;
     const char *base = (const char *)cube;
     int count = 0;
-    // sign bits of the nine candidates: "c >= 0 ? v : -v" becomes v ^ sign(c) (they differ only for
-    // c = -0, which can be the major coordinate only when the whole direction is zero)
-    unsigned SX[3], SY[3], SZ[3], RX[3], RY[3], RZ[3];  // R*: first texel row of the face a candidate selects
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        SX[k] = __builtin_bit_cast(unsigned, X[k]) & 0x80000000u;
-        SY[k] = __builtin_bit_cast(unsigned, Y[k]) & 0x80000000u;
-        SZ[k] = __builtin_bit_cast(unsigned, Z[k]) & 0x80000000u;
-        RX[k] = __umul24(SX[k] >> 31, (unsigned)res);
-        RY[k] = __umul24(2u | (SY[k] >> 31), (unsigned)res);
-        RZ[k] = __umul24(4u | (SZ[k] >> 31), (unsigned)res);
-    }
+    // "c >= 0 ? v : -v" is v ^ sign(c) (they differ only for c = -0, which can be the major
+    // coordinate only when the whole direction is zero)
 #define VKR_TAP(gx, gy, gz)                                                                        \
     {                                                                                              \
-        const float rx = X[gx], ry = Y[gy], rz = Z[gz], ax = AX[gx], ay = AY[gy], az = AZ[gz];     \
+        const float rx = X[gx], ry = Y[gy], rz = Z[gz];                                            \
+        const float ax = __builtin_fabsf(rx), ay = __builtin_fabsf(ry), az = __builtin_fabsf(rz);  \
+        const unsigned bx = __builtin_bit_cast(unsigned, rx), by = __builtin_bit_cast(unsigned, ry), bz = __builtin_bit_cast(unsigned, rz); \
         const bool zm = (az >= ax) & (az >= ay);                                                   \
         const bool ym = !zm & (ay >= ax);                                                          \
-        const float scz = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, rx) ^ SZ[gz]);    \
-        const float scx = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, rz) ^ SX[gx] ^ 0x80000000u); \
-        const float tcy = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, rz) ^ SY[gy]);    \
-        const float ima = zm ? IZ[gz] : (ym ? IY[gy] : IX[gx]);                                    \
+        const float ima = fast_rcp_rn(zm ? az : (ym ? ay : ax));                                   \
+        const unsigned smaj = (zm ? bz : (ym ? by : bx)) >> 31;                                    \
+        const float scz = __builtin_bit_cast(float, bx ^ (bz & 0x80000000u));                      \
+        const float scx = __builtin_bit_cast(float, bz ^ (~bx & 0x80000000u));                     \
+        const float tcy = __builtin_bit_cast(float, bz ^ (by & 0x80000000u));                      \
         const float sc = zm ? scz : (ym ? rx : scx);                                               \
         const float tc = ym ? tcy : -ry;                                                           \
-        const unsigned row0 = zm ? RZ[gz] : (ym ? RY[gy] : RX[gx]);                                \
-        const unsigned i4 = (unsigned)face_texel(sc, ima, fres, res) * 4u;                         \
-        const unsigned j = (unsigned)face_texel(tc, ima, fres, res);                               \
-        const unsigned off = __umul24(row0 + j, res4) + i4;                                        \
+        const unsigned face = (zm ? 4u : (ym ? 2u : 0u)) | smaj;                                   \
+        const unsigned off = face * face_bytes + row_bytes<TILED>(face_texel(tc, ima, fres, res), (unsigned)res) \
+                             + col_bytes<TILED>(face_texel(sc, ima, fres, res));                   \
         const float closest = *(const float *)(base + off) * 25.0f;                                \
         count += cur > closest ? 1 : 0;                                                            \
     }
-    VKR_GRID20(VKR_TAP)
+#define VKR_FENCE asm volatile("" : "+v"(count));  /* at most five loads in flight */
+    VKR_TAP(2, 2, 2) VKR_TAP(2, 0, 2) VKR_TAP(0, 0, 2) VKR_TAP(0, 2, 2) VKR_TAP(2, 2, 0) VKR_FENCE
+    VKR_TAP(2, 0, 0) VKR_TAP(0, 0, 0) VKR_TAP(0, 2, 0) VKR_TAP(2, 2, 1) VKR_TAP(2, 0, 1) VKR_FENCE
+    VKR_TAP(0, 0, 1) VKR_TAP(0, 2, 1) VKR_TAP(2, 1, 2) VKR_TAP(0, 1, 2) VKR_TAP(2, 1, 0) VKR_FENCE
+    VKR_TAP(0, 1, 0) VKR_TAP(1, 2, 2) VKR_TAP(1, 0, 2) VKR_TAP(1, 0, 0) VKR_TAP(1, 2, 0)
+#undef VKR_FENCE
 #undef VKR_TAP
     return count;
 }
@@ -241,32 +254,35 @@ VKR_DEV int common_face(const float (&X)[3], const float (&Y)[3], const float (&
 }
 
 // Workgroups are dealt to the 8 XCDs round-robin by id, and each XCD has its own L2.  This maps
-// block id -> tile so that each XCD shades one contiguous run of tiles, ordered in 16-tile-wide
-// column blocks: the workgroups resident on an XCD at one time cover a compact screen region and
+// block id -> tile so that each XCD shades one contiguous run of tiles, ordered in 64-tile-wide
+// (512-pixel) column blocks: the workgroups resident on an XCD at one time cover a compact screen region and
 // therefore a compact region of every shadow map, which keeps their shared texels in that L2.
 VKR_DEV void tile_of_block(unsigned b, int tiles_x, int tiles_y, int &tx, int &ty)
 {
+    constexpr unsigned CB = 64u;
     const unsigned total = (unsigned)tiles_x * tiles_y;
     const unsigned xcd = b & 7u, q = b >> 3;
     // ids 0..total-1 dealt round-robin: XCD k owns ceil((total - k) / 8) of them
     const unsigned base = total >> 3, rem = total & 7u;
     const unsigned v = xcd * base + min(xcd, rem) + q;  // position in the column-block order
-    const unsigned block_tiles = 16u * (unsigned)tiles_y;
-    const unsigned cb = min(v / block_tiles, (unsigned)(tiles_x - 1) / 16u);
+    const unsigned block_tiles = CB * (unsigned)tiles_y;
+    const unsigned cb = min(v / block_tiles, (unsigned)(tiles_x - 1) / CB);
     const unsigned r = v - cb * block_tiles;
-    const unsigned cbw = min(16u, (unsigned)tiles_x - cb * 16u);
+    const unsigned cbw = min(CB, (unsigned)tiles_x - cb * CB);
     ty = (int)(r / cbw);
-    tx = (int)(cb * 16u + r % cbw);
+    tx = (int)(cb * CB + r % cbw);
 }
 
-__global__ __launch_bounds__(256) void shade_kernel(const ShadeParams p)
+// 91 VGPRs: five waves per SIMD.  (Six need spills inside the light loop and run slower.)
+template <bool TILED>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void shade_kernel(const ShadeParams p)
 {
-    // 16x16 pixel tile per workgroup; wave w covers the 8x8 block (w & 1, w >> 1) of the tile
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // one wave per workgroup, one 8x8-pixel tile per wave
+    const int lane = threadIdx.x;
     int tile_x, tile_y;
     tile_of_block(blockIdx.x, p.tiles_x, p.tiles_y, tile_x, tile_y);
-    const int x = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int y = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int x = tile_x * 8 + (lane & 7);
+    const int y = tile_y * 8 + (lane >> 3);
     if (x >= p.width || y >= p.rows) return;
     const size_t px = (size_t)y * p.width + x;
 
@@ -364,6 +380,25 @@ __global__ __launch_bounds__(256) void shade_kernel(const ShadeParams p)
             const f3 Lv = sub3(lp, pos);
             float dist, inv_dist;
             sqrt_and_rcp_rn(dot3(Lv, Lv), dist, inv_dist);
+            // light.frag:121-141; |pos - lp| equals |lp - pos| bit for bit
+            const float cur = dist - 0.15f;
+            const float X[3] = {pos.x - lp.x - disk, pos.x - lp.x, pos.x - lp.x + disk};
+            const float Y[3] = {pos.y - lp.y - disk, pos.y - lp.y, pos.y - lp.y + disk};
+            const float Z[3] = {pos.z - lp.z - disk, pos.z - lp.z, pos.z - lp.z + disk};
+            const float *cube = p.cube_shadow + (size_t)li * 6 * face_stride;
+            const int face = common_face(X, Y, Z);
+            const int face0 = __builtin_amdgcn_readfirstlane(face);
+            int count;
+            if (face0 >= 0 && __all(face == face0)) {
+                const float *fb = cube + (size_t)face0 * face_stride;
+                const bool neg = face0 & 1;
+                if (face0 >= 4) count = taps_one_face<2, TILED>(fb, p.cube_res, X, Y, Z, neg, cur);
+                else if (face0 >= 2) count = taps_one_face<1, TILED>(fb, p.cube_res, X, Y, Z, neg, cur);
+                else count = taps_one_face<0, TILED>(fb, p.cube_res, X, Y, Z, neg, cur);
+            } else {
+                count = taps_any_face<TILED>(cube, p.cube_res, X, Y, Z, cur);
+            }
+            asm volatile("" : "+v"(count));  // keep the BRDF terms below out of the tap section
             const f3 L = scale3(Lv, inv_dist);
             const f3 Hv = add3(V, L);
             float hlen, inv_hlen;
@@ -378,24 +413,6 @@ __global__ __launch_bounds__(256) void shade_kernel(const ShadeParams p)
             const float isd = fast_rcp_rn(fma_(fourNdotV, NdotL, 0.0001f));
             const float DG = D * G;
 
-            // light.frag:121-141; |pos - lp| equals |lp - pos| bit for bit
-            const float cur = dist - 0.15f;
-            const float X[3] = {pos.x - lp.x - disk, pos.x - lp.x, pos.x - lp.x + disk};
-            const float Y[3] = {pos.y - lp.y - disk, pos.y - lp.y, pos.y - lp.y + disk};
-            const float Z[3] = {pos.z - lp.z - disk, pos.z - lp.z, pos.z - lp.z + disk};
-            const float *cube = p.cube_shadow + (size_t)li * 6 * face_stride;
-            const int face = common_face(X, Y, Z);
-            const int face0 = __builtin_amdgcn_readfirstlane(face);
-            int count;
-            if (face0 >= 0 && __all(face == face0)) {
-                const float *fb = cube + (size_t)face0 * face_stride;
-                const bool neg = face0 & 1;
-                if (face0 >= 4) count = taps_one_face<2>(fb, p.cube_res, X, Y, Z, neg, cur);
-                else if (face0 >= 2) count = taps_one_face<1>(fb, p.cube_res, X, Y, Z, neg, cur);
-                else count = taps_one_face<0>(fb, p.cube_res, X, Y, Z, neg, cur);
-            } else {
-                count = taps_any_face(cube, p.cube_res, X, Y, Z, cur);
-            }
             const float lit = 1.0f - (float)count * (1.0f / 20.0f);
 
             const float o0 = ((fma_((1.0f - F.x) * albedo.x, INV_PI, (DG * F.x) * isd) * (lc.x * att)) * lit) * NdotL;
@@ -414,7 +431,37 @@ __global__ __launch_bounds__(256) void shade_kernel(const ShadeParams p)
     p.out_threshold[px] = pack4(t0, t1, t2, 1.0f);
 }
 
+// Row-major face -> 8x4-texel tiles.  Eight lanes move one tile (16 bytes each), so a wave writes
+// eight consecutive tiles (1 KiB contiguous) and reads four 256-byte row segments.
+__global__ __launch_bounds__(256) void tile_depth_kernel(const float4 *src, float4 *dst, int res, unsigned tiles_per_face, unsigned total_tiles)
+{
+    const unsigned t = (blockIdx.x * 256u + threadIdx.x) >> 3;  // tile index over all faces
+    if (t >= total_tiles) return;
+    const unsigned q = threadIdx.x & 7u;                        // 16-byte piece of the tile: row q >> 1, half q & 1
+    const unsigned face = t / tiles_per_face, tf = t - face * tiles_per_face;
+    const unsigned tiles_x = (unsigned)res >> 3;
+    const unsigned ty = tf / tiles_x, tx = tf - ty * tiles_x;
+    const size_t texel = (size_t)face * res * res + (size_t)(ty * 4u + (q >> 1)) * res + tx * 8u + (q & 1u) * 4u;
+    dst[(size_t)t * 8u + q] = src[texel >> 2];
+}
+
 }  // namespace vkr
+
+extern "C" int32_t vkr_tile_depth_cubes(const float *linear, float *tiled, int32_t n_faces, int32_t res, void *stream)
+{
+    using namespace vkr;
+    VKR_REQUIRE(linear && tiled, "vkr_tile_depth_cubes: an image is null");
+    VKR_REQUIRE(n_faces >= 0 && res > 0 && res % 8 == 0 && res <= 8192, "vkr_tile_depth_cubes: %d faces of size %d (size must be a multiple of 8, at most 8192)", n_faces, res);
+    const size_t bytes = (size_t)n_faces * res * res * 4;
+    const char *a = (const char *)linear, *b = (const char *)tiled;
+    VKR_REQUIRE(a + bytes <= b || b + bytes <= a, "vkr_tile_depth_cubes: source and destination overlap");
+    const uint64_t tiles_per_face = (uint64_t)(res / 8) * (res / 4), total = tiles_per_face * (uint64_t)n_faces;
+    VKR_REQUIRE(total < (1ull << 28), "vkr_tile_depth_cubes: too many texels for one call");
+    if (total == 0) return VKR_OK;
+    hipLaunchKernelGGL(tile_depth_kernel, dim3((unsigned)((total * 8 + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       (const float4 *)linear, (float4 *)tiled, res, (unsigned)tiles_per_face, (unsigned)total);
+    return launch_status("vkr_tile_depth_cubes");
+}
 
 extern "C" int32_t vkr_shade(const VkrShadeArgs *a, void *stream)
 {
@@ -430,6 +477,8 @@ extern "C" int32_t vkr_shade(const VkrShadeArgs *a, void *stream)
     VKR_REQUIRE((int64_t)a->dir_res * a->dir_res < (1ll << 31), "vkr_shade: directional shadow map too large");
     if (a->coverage_mode != VKR_COVERAGE_FULLSCREEN)
         return fail(VKR_ERR_UNSUPPORTED, "vkr_shade: coverage mode %d is not implemented", a->coverage_mode);
+    VKR_REQUIRE(a->cube_layout == VKR_CUBE_LAYOUT_LINEAR || a->cube_layout == VKR_CUBE_LAYOUT_TILED_8X4, "vkr_shade: unknown cube shadow layout %d", a->cube_layout);
+    VKR_REQUIRE(a->cube_layout == VKR_CUBE_LAYOUT_LINEAR || a->n_lights == 0 || a->cube_res % 8 == 0, "vkr_shade: the tiled cube shadow layout needs a face size that is a multiple of 8 (got %d)", a->cube_res);
 
     ShadeParams p;
     p.width = a->width; p.rows = a->rows;
@@ -449,8 +498,12 @@ extern "C" int32_t vkr_shade(const VkrShadeArgs *a, void *stream)
     }
     for (int i = 0; i < 16; i++) p.light_space[i] = a->scene.light_space_matrix[i];
 
-    p.tiles_x = (a->width + 15) / 16; p.tiles_y = (a->rows + 15) / 16;
+    p.tiles_x = (a->width + 7) / 8; p.tiles_y = (a->rows + 7) / 8;
     VKR_REQUIRE((int64_t)p.tiles_x * p.tiles_y < (1ll << 31), "vkr_shade: strip too large");
-    hipLaunchKernelGGL(shade_kernel, dim3((unsigned)(p.tiles_x * p.tiles_y)), dim3(256), 0, as_stream(stream), p);
+    const dim3 grid((unsigned)(p.tiles_x * p.tiles_y));
+    if (a->cube_layout == VKR_CUBE_LAYOUT_TILED_8X4)
+        hipLaunchKernelGGL(shade_kernel<true>, grid, dim3(64), 0, as_stream(stream), p);
+    else
+        hipLaunchKernelGGL(shade_kernel<false>, grid, dim3(64), 0, as_stream(stream), p);
     return launch_status("vkr_shade");
 }

@@ -56,9 +56,21 @@ class DeviceFrame:
     prefilter: torch.Tensor
     brdf_lut: torch.Tensor
     background: torch.Tensor | None = None
+    cube_layout: int = _lib.CUBE_LAYOUT_LINEAR
 
     @staticmethod
-    def upload(f: FrameInputs, device) -> "DeviceFrame":
+    def upload(f: FrameInputs, device, tiled: bool | None = None) -> "DeviceFrame":
+        """`tiled`: store the point-shadow cubes as 8x4-texel tiles (None: whenever the face size allows)."""
+        d = DeviceFrame._upload_linear(f, device)
+        if tiled is None:
+            tiled = d.cube_shadow.shape[-1] % 8 == 0
+        if tiled and d.n_lights > 0:
+            d.cube_shadow = tile_depth_cubes(d.cube_shadow)
+            d.cube_layout = _lib.CUBE_LAYOUT_TILED_8X4
+        return d
+
+    @staticmethod
+    def _upload_linear(f: FrameInputs, device) -> "DeviceFrame":
         lights = torch.from_numpy(np.frombuffer(f.lights.tobytes(), dtype=np.uint8).copy()).to(device)
         return DeviceFrame(
             f.width, f.height,
@@ -67,6 +79,15 @@ class DeviceFrame:
             f.scene, lights, len(f.lights),
             torch.from_numpy(f.dir_shadow).to(device), torch.from_numpy(f.cube_shadow).to(device),
             to_device_f16(f.irradiance, device), to_device_f16(f.prefilter, device), to_device_f16(f.brdf_lut, device))
+
+
+def tile_depth_cubes(linear: torch.Tensor) -> torch.Tensor:
+    """[..., res, res] float32 depth faces, row-major -> the same faces as 8x4-texel tiles (new tensor)."""
+    lib = _lib.load()
+    res = linear.shape[-1]
+    out = torch.empty_like(linear)
+    _lib.check(lib.vkr_tile_depth_cubes(_ptr(linear), _ptr(out), linear.numel() // (res * res), res, _stream()))
+    return out
 
 
 def _scene_struct(scene: np.ndarray) -> _lib.SceneInfo:
@@ -84,7 +105,7 @@ def shade(f: DeviceFrame, out_color: torch.Tensor, out_threshold: torch.Tensor) 
     a.scene = _scene_struct(f.scene)
     a.lights, a.n_lights, a.coverage_mode = _ptr(f.lights), f.n_lights, _lib.COVERAGE_FULLSCREEN
     a.dir_shadow, a.dir_res = _ptr(f.dir_shadow), f.dir_shadow.shape[-1]
-    a.cube_shadow, a.cube_res = _ptr(f.cube_shadow), f.cube_shadow.shape[-1]
+    a.cube_shadow, a.cube_res, a.cube_layout = _ptr(f.cube_shadow), f.cube_shadow.shape[-1], f.cube_layout
     a.irradiance, a.irr_res = _ptr(f.irradiance), f.irradiance.shape[1]
     a.prefilter, a.pref_res = _ptr(f.prefilter), f.prefilter.shape[1]
     a.brdf_lut, a.lut_res = _ptr(f.brdf_lut), f.brdf_lut.shape[0]
