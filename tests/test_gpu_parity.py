@@ -44,6 +44,7 @@ FRAMES = [
     (12, 201, 37, 3, 32, 128),     # ragged: odd width, height not a multiple of anything
     (13, 64, 64, 0, 16, 64),       # no point lights at all
     (14, 96, 80, 33, 16, 64),      # more lights than the reference's MaxLights
+    (16, 88, 48, 2, 24, 64),       # cube faces whose size is not a power of two
 ]
 
 

@@ -135,13 +135,16 @@ template <bool TILED> VKR_DEV unsigned row_bytes(int j, unsigned res)
     T(1, 2, 2) T(1, 0, 2) T(1, 0, 0) T(1, 2, 0)
 #define VKR_GRID20(T) VKR_GRID20A(T) VKR_GRID20B(T)
 
-// Texel coordinate (already clamped, as a byte offset when scale = 4) of face coordinate c / ma
+// Texel coordinate (already clamped) of face coordinate c / ma.  POW2: the face size is a power
+// of two, so scaling by it is exact and (q * 0.5 + 0.5) * res == q * (res/2) + res/2 bit for bit.
+template <bool POW2>
 VKR_DEV int face_texel(float c, float ima, float fres, int res)
 {
-    float s = fma_(c * ima, 0.5f, 0.5f);
+    const float q = c * ima;
+    const float scaled = POW2 ? fma_(q, 0.5f * fres, 0.5f * fres) : fma_(q, 0.5f, 0.5f) * fres;
     int i, r;
     // floor + convert in one instruction, clamp to [0, res-1] in one instruction
-    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(i) : "v"(s * fres));
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(i) : "v"(scaled));
     asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(i), "s"(res - 1));
     return r;
 }
@@ -150,7 +153,7 @@ VKR_DEV int face_texel(float c, float ima, float fres, int res)
 // the wave lies on cube face `face` (wave-uniform).  U, W are the coordinates that become sc, tc
 // (sign already applied), IM the reciprocals of |major coordinate|; the index triple of a tap is
 // permuted so that (iu, iw, im) index U, W, IM.
-template <int AXIS, bool TILED>
+template <int AXIS, bool TILED, bool POW2>
 VKR_DEV int taps_one_face(const float *face_base, int res, const float (&X)[3], const float (&Y)[3], const float (&Z)[3], bool neg, float cur)
 {
     const float fres = (float)res;
@@ -169,8 +172,8 @@ VKR_DEV int taps_one_face(const float *face_base, int res, const float (&X)[3], 
             if (AXIS == 2) { u = neg ? -X[a] : X[a]; w = -Y[a]; }
             else if (AXIS == 1) { u = X[a]; w = neg ? -Z[a] : Z[a]; }
             else { u = neg ? Z[a] : -Z[a]; w = -Y[a]; }
-            I[a][m] = col_bytes<TILED>(face_texel(u, IM[m], fres, res));
-            J[a][m] = row_bytes<TILED>(face_texel(w, IM[m], fres, res), (unsigned)res);
+            I[a][m] = col_bytes<TILED>(face_texel<POW2>(u, IM[m], fres, res));
+            J[a][m] = row_bytes<TILED>(face_texel<POW2>(w, IM[m], fres, res), (unsigned)res);
         }
     int count = 0;
     const char *base = (const char *)face_base;
@@ -192,7 +195,7 @@ VKR_DEV int taps_one_face(const float *face_base, int res, const float (&X)[3], 
 // shadowSampler: NEAREST on the face the direction's major axis selects).  This path runs for
 // the few waves that straddle a face edge; it recomputes everything per tap so that it needs no
 // more registers than the one-face path, which sets the kernel's occupancy.
-template <bool TILED>
+template <bool TILED, bool POW2>
 VKR_DEV int taps_any_face(const float *cube, int res, const float (&X)[3], const float (&Y)[3], const float (&Z)[3], float cur)
 {
     const float fres = (float)res;
@@ -216,8 +219,8 @@ VKR_DEV int taps_any_face(const float *cube, int res, const float (&X)[3], const
         const float sc = zm ? scz : (ym ? rx : scx);                                               \
         const float tc = ym ? tcy : -ry;                                                           \
         const unsigned face = (zm ? 4u : (ym ? 2u : 0u)) | smaj;                                   \
-        const unsigned off = face * face_bytes + row_bytes<TILED>(face_texel(tc, ima, fres, res), (unsigned)res) \
-                             + col_bytes<TILED>(face_texel(sc, ima, fres, res));                   \
+        const unsigned off = face * face_bytes + row_bytes<TILED>(face_texel<POW2>(tc, ima, fres, res), (unsigned)res) \
+                             + col_bytes<TILED>(face_texel<POW2>(sc, ima, fres, res));                   \
         const float closest = *(const float *)(base + off) * 25.0f;                                \
         count += cur > closest ? 1 : 0;                                                            \
     }
@@ -273,9 +276,11 @@ VKR_DEV void tile_of_block(unsigned b, int tiles_x, int tiles_y, int &tx, int &t
     tx = (int)(cb * CB + r % cbw);
 }
 
-// 91 VGPRs: five waves per SIMD.  (Six need spills inside the light loop and run slower.)
-template <bool TILED>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void shade_kernel(const ShadeParams p)
+// Six waves per SIMD (80 VGPRs): the ten values the register allocator spills for that are used
+// only before and after the light loop, which itself touches no scratch memory.  Measured at
+// 4K / 64 lights: 4 waves 5.5 ms, 5 waves 4.6, 6 waves 4.5, 7 waves (spills inside the loop) 4.6.
+template <bool TILED, bool POW2>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void shade_kernel(const ShadeParams p)
 {
     // one wave per workgroup, one 8x8-pixel tile per wave
     const int lane = threadIdx.x;
@@ -380,6 +385,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             const f3 Lv = sub3(lp, pos);
             float dist, inv_dist;
             sqrt_and_rcp_rn(dot3(Lv, Lv), dist, inv_dist);
+            const f3 L = scale3(Lv, inv_dist);
+            const float NdotL = max0(dot3(N, L));
             // light.frag:121-141; |pos - lp| equals |lp - pos| bit for bit
             const float cur = dist - 0.15f;
             const float X[3] = {pos.x - lp.x - disk, pos.x - lp.x, pos.x - lp.x + disk};
@@ -388,18 +395,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             const float *cube = p.cube_shadow + (size_t)li * 6 * face_stride;
             const int face = common_face(X, Y, Z);
             const int face0 = __builtin_amdgcn_readfirstlane(face);
-            int count;
-            if (face0 >= 0 && __all(face == face0)) {
+            // The shadow factor multiplies a product whose last factor is N.L; where N.L is zero in
+            // every lane the result is the same zero (or NaN) whatever the taps say, so a wave that
+            // faces away from the light skips them.
+            int count = 0;
+            if (!__any(NdotL > 0.0f)) {
+            } else if (face0 >= 0 && __all(face == face0)) {
                 const float *fb = cube + (size_t)face0 * face_stride;
                 const bool neg = face0 & 1;
-                if (face0 >= 4) count = taps_one_face<2, TILED>(fb, p.cube_res, X, Y, Z, neg, cur);
-                else if (face0 >= 2) count = taps_one_face<1, TILED>(fb, p.cube_res, X, Y, Z, neg, cur);
-                else count = taps_one_face<0, TILED>(fb, p.cube_res, X, Y, Z, neg, cur);
+                if (face0 >= 4) count = taps_one_face<2, TILED, POW2>(fb, p.cube_res, X, Y, Z, neg, cur);
+                else if (face0 >= 2) count = taps_one_face<1, TILED, POW2>(fb, p.cube_res, X, Y, Z, neg, cur);
+                else count = taps_one_face<0, TILED, POW2>(fb, p.cube_res, X, Y, Z, neg, cur);
             } else {
-                count = taps_any_face<TILED>(cube, p.cube_res, X, Y, Z, cur);
+                count = taps_any_face<TILED, POW2>(cube, p.cube_res, X, Y, Z, cur);
             }
             asm volatile("" : "+v"(count));  // keep the BRDF terms below out of the tap section
-            const f3 L = scale3(Lv, inv_dist);
             const f3 Hv = add3(V, L);
             float hlen, inv_hlen;
             sqrt_and_rcp_rn(dot3(Hv, Hv), hlen, inv_hlen);
@@ -407,7 +417,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             const float att = rcp_rn_checked(dist * dist);
             // the denominators below lie in [1e-4, 8]: well inside fast_rcp_rn's exact domain
             const float D = normal_distribution(dot3(N, H), a2, rcp_fast);
-            const float NdotL = max0(dot3(N, L));
             const float G = g1V * geometry_schlick(NdotL, k, omk, rcp_fast);
             const f3 F = fresnel_schlick(max0(dot3(H, V)), F0, omF0);
             const float isd = fast_rcp_rn(fma_(fourNdotV, NdotL, 0.0001f));
@@ -501,9 +510,10 @@ extern "C" int32_t vkr_shade(const VkrShadeArgs *a, void *stream)
     p.tiles_x = (a->width + 7) / 8; p.tiles_y = (a->rows + 7) / 8;
     VKR_REQUIRE((int64_t)p.tiles_x * p.tiles_y < (1ll << 31), "vkr_shade: strip too large");
     const dim3 grid((unsigned)(p.tiles_x * p.tiles_y));
-    if (a->cube_layout == VKR_CUBE_LAYOUT_TILED_8X4)
-        hipLaunchKernelGGL(shade_kernel<true>, grid, dim3(64), 0, as_stream(stream), p);
-    else
-        hipLaunchKernelGGL(shade_kernel<false>, grid, dim3(64), 0, as_stream(stream), p);
+    const bool tiled = a->cube_layout == VKR_CUBE_LAYOUT_TILED_8X4;
+    const bool pow2 = a->n_lights > 0 && (a->cube_res & (a->cube_res - 1)) == 0;
+    auto kernel = tiled ? (pow2 ? shade_kernel<true, true> : shade_kernel<true, false>)
+                        : (pow2 ? shade_kernel<false, true> : shade_kernel<false, false>);
+    hipLaunchKernelGGL(kernel, grid, dim3(64), 0, as_stream(stream), p);
     return launch_status("vkr_shade");
 }
