@@ -168,10 +168,17 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # One rank per GPU over RCCL.  VKR_DIST_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs
+    # than ranks (ranks then share devices; RCCL refuses two ranks on one device).
+    backend = os.environ.get("VKR_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     f, dev_frame = build_inputs(rank, device, HEIGHT, args.lights, args.cube_res, args.dir_res)
     plan = StripPlan.make(rank, world, HEIGHT * world)
