@@ -185,10 +185,11 @@ VKR_DEV int taps_one_face(const float *face_base, int res, const float (&X)[3], 
         count += cur > closest ? 1 : 0;                                                  \
     }
     VKR_GRID20A(VKR_TAP)
-    asm volatile("" : "+v"(count));  // two batches of ten loads: fewer registers hold values in flight
+    const int count_a = count;  // two independent chains of ten adds instead of one of twenty
+    count = 0;
     VKR_GRID20B(VKR_TAP)
 #undef VKR_TAP
-    return count;
+    return count + count_a;
 }
 
 // The same count with the cube face chosen per tap and per lane (light.frag:133 through
@@ -409,7 +410,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             } else {
                 count = taps_any_face<TILED, POW2>(cube, p.cube_res, X, Y, Z, cur);
             }
-            asm volatile("" : "+v"(count));  // keep the BRDF terms below out of the tap section
             const f3 Hv = add3(V, L);
             float hlen, inv_hlen;
             sqrt_and_rcp_rn(dot3(Hv, Hv), hlen, inv_hlen);
