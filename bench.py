@@ -93,11 +93,12 @@ def time_ibl(device) -> dict:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         ev[0].record()
         P.equirect_to_cube(src, _lib.SRC_RGBA16F, env)
+        tiled = P.tile_env_cube(env)  # the copy the two sampling passes read; counted with the equirect stage
         ev[1].record()
-        P.irradiance(env, irr, _lib.IRRADIANCE_SEQUENTIAL)
+        P.irradiance(tiled, irr, _lib.IRRADIANCE_SEQUENTIAL, env_layout=_lib.ENV_LAYOUT_TILED_4X4)
         ev[2].record()
         for m in range(5):
-            P.prefilter(env, pres[m], m / 4.0)
+            P.prefilter(tiled, pres[m], m / 4.0, env_layout=_lib.ENV_LAYOUT_TILED_4X4)
         ev[3].record()
         P.brdf_lut(lut)
         ev[4].record()
@@ -108,7 +109,8 @@ def time_ibl(device) -> dict:
     t = run()
     return {"equirect_ms": round(t[0], 3), "irradiance_ms": round(t[1], 3), "prefilter_ms": round(t[2], 3),
             "brdf_lut_ms": round(t[3], 3), "total_ms": round(sum(t), 3),
-            "config": "equirect 4096x2048 RGBA16F -> env 2048^2, irradiance 64^2, prefilter 128^2 x5 mips, LUT 512^2"}
+            "config": "equirect 4096x2048 RGBA16F -> env 2048^2 (+ 4x4-tiled copy), irradiance 64^2 in the shader's summation order, "
+                      "prefilter 128^2 x5 mips, LUT 512^2"}
 
 
 def measured_traffic(lights: int, cube_res: int, dir_res: int) -> dict:

@@ -75,6 +75,11 @@ typedef struct VkrLightInfo {
 #define VKR_CUBE_LAYOUT_TILED_8X4 1 /* each face as row-major 8x4-texel tiles of 128 bytes; face size % 8 == 0;
                                        made from the linear layout by vkr_tile_depth_cubes() */
 
+/* Memory layout of the RGBA16F environment cube read by the irradiance and prefilter passes. */
+#define VKR_ENV_LAYOUT_LINEAR 0    /* [face][row][column], tight */
+#define VKR_ENV_LAYOUT_TILED_4X4 1 /* each face as row-major 4x4-texel tiles of 128 bytes; face size % 4 == 0;
+                                      made from the linear layout by vkr_tile_rgba16f_faces() */
+
 #define VKR_WRAP_REPEAT 0 /* textureSampler, VulkanHelper.cs:123-154 */
 #define VKR_WRAP_CLAMP 1  /* bloomSampler,   VulkanHelper.cs:156-187 */
 
@@ -160,11 +165,15 @@ VKR_EXPORT int32_t vkr_bloomv_postprocess(const VkrBloomPostArgs *args, void *st
 /* Replaces CreateSkyboxCubemap's six draws (VulkanRenderer.cs:653-732). */
 VKR_EXPORT int32_t vkr_ibl_equirect_to_cube(const void *src, int32_t src_w, int32_t src_h, int32_t src_format,
                                  void *cube, int32_t n, int32_t row_begin, int32_t row_end, void *stream);
+/* Re-lays `n_faces` RGBA16F faces of `n`^2 texels from VKR_ENV_LAYOUT_LINEAR to VKR_ENV_LAYOUT_TILED_4X4
+ * (n % 4 == 0; src and dst must not overlap).  No counterpart in the reference, whose images are
+ * OPTIMAL-tiled by the driver. */
+VKR_EXPORT int32_t vkr_tile_rgba16f_faces(const void *linear, void *tiled, int32_t n_faces, int32_t n, void *stream);
 /* Replaces CreateIrradianceCubemap's six draws (VulkanRenderer.cs:734-813). */
-VKR_EXPORT int32_t vkr_ibl_irradiance(const void *env, int32_t env_n, void *out, int32_t n, int32_t order,
+VKR_EXPORT int32_t vkr_ibl_irradiance(const void *env, int32_t env_n, int32_t env_layout, void *out, int32_t n, int32_t order,
                            int32_t row_begin, int32_t row_end, void *stream);
 /* Replaces the six draws of one mip of CreatePrefilteredCubemap (VulkanRenderer.cs:855-884). */
-VKR_EXPORT int32_t vkr_ibl_prefilter(const void *env, int32_t env_n, void *out, int32_t n, float roughness,
+VKR_EXPORT int32_t vkr_ibl_prefilter(const void *env, int32_t env_n, int32_t env_layout, void *out, int32_t n, float roughness,
                           int32_t row_begin, int32_t row_end, void *stream);
 /* Replaces CreateBRDFLUTTexture's draw (VulkanRenderer.cs:966-989); rows of the n^2 RG16F image. */
 VKR_EXPORT int32_t vkr_ibl_brdf_lut(void *out, int32_t n, int32_t row_begin, int32_t row_end, void *stream);

@@ -30,4 +30,10 @@ timed("irradiance sequential", lambda: P.irradiance(env, irr, _lib.IRRADIANCE_SE
 timed("irradiance phi slices", lambda: P.irradiance(env, irr, _lib.IRRADIANCE_PHI_SLICES), 3)
 for m in range(5):
     timed(f"prefilter mip {m} r={m / 4}", lambda m=m: P.prefilter(env, pres[m], m / 4.0))
+timed("tile env", lambda: P.tile_env_cube(env))
+tiled = P.tile_env_cube(env)
+T = _lib.ENV_LAYOUT_TILED_4X4
+timed("irradiance sequential, tiled", lambda: P.irradiance(tiled, irr, _lib.IRRADIANCE_SEQUENTIAL, env_layout=T), 3)
+for m in range(5):
+    timed(f"prefilter mip {m}, tiled", lambda m=m: P.prefilter(tiled, pres[m], m / 4.0, env_layout=T))
 timed("brdf lut", lambda: P.brdf_lut(lut))

@@ -373,3 +373,34 @@ def test_tiled_cube_layout(gpu, oracle):
         P.shade(d, color, thr)
     with pytest.raises(_lib.VkrError):
         P.tile_depth_cubes(d.cube_shadow)
+
+
+def test_tiled_environment_cube(gpu, oracle):
+    """vkr_tile_rgba16f_faces against the layout's definition, and the irradiance / prefilter passes
+    reading the tiled cube give the bits they give on the row-major one (= the oracle's)."""
+    torch, P = _torch(), _passes()
+    n = 64
+    env = synth.make_env_cube(np.random.default_rng(33), n)
+    dev_env = P.to_device_f16(env, gpu)
+    tiled = P.tile_env_cube(dev_env)
+    got = P.f16_bits(tiled).reshape(6, n * n, 4)
+    j, i = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    index = ((j >> 2) * (n >> 2) + (i >> 2)) * 16 + (j & 3) * 4 + (i & 3)
+    want = np.empty_like(got)
+    want[:, index.ravel()] = env.reshape(6, n * n, 4)
+    assert np.array_equal(got, want)
+
+    T = _lib.ENV_LAYOUT_TILED_4X4
+    irr = torch.empty((6, 8, 8, 4), dtype=torch.float16, device=gpu)
+    for order in (0, 1):
+        P.irradiance(tiled, irr, order, env_layout=T)
+        assert_bits_equal(P.f16_bits(irr), oracle.irradiance(env, 8, order), f"irradiance from the tiled cube, order {order}")
+    pre = torch.empty((6, 16, 16, 4), dtype=torch.float16, device=gpu)
+    for rough in (0.0, 0.5, 1.0):
+        P.prefilter(tiled, pre, rough, env_layout=T)
+        assert_bits_equal(P.f16_bits(pre), oracle.prefilter(env, 16, rough), f"prefilter from the tiled cube, roughness {rough}")
+    odd = P.to_device_f16(synth.make_env_cube(np.random.default_rng(34), 6), gpu)  # 6 is not a multiple of 4
+    with pytest.raises(_lib.VkrError):
+        P.tile_env_cube(odd)
+    with pytest.raises(_lib.VkrError):
+        P.irradiance(odd, irr, 0, env_layout=T)

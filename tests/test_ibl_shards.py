@@ -37,11 +37,14 @@ class OracleIblBackend:
         flat_out, flat_whole = self._bits(out).reshape(-1, n, out.shape[-1]), whole.reshape(-1, n, whole.shape[-1])
         flat_out[rows[0]:rows[1]] = flat_whole[rows[0]:rows[1]]
 
-    def irradiance(self, env, out, rows):
+    def sampling_copy(self, env):
+        return env, 0
+
+    def irradiance(self, env, out, rows, env_layout=0):
         from tests import oracle
         self._rows(out, oracle.irradiance(self._bits(env), out.shape[1], 0), rows)
 
-    def prefilter(self, env, out, roughness, rows):
+    def prefilter(self, env, out, roughness, rows, env_layout=0):
         from tests import oracle
         self._rows(out, oracle.prefilter(self._bits(env), out.shape[1], roughness), rows)
 

@@ -16,6 +16,7 @@ VKR_OK = 0
 VKR_ERR_INVALID, VKR_ERR_HIP, VKR_ERR_UNSUPPORTED, VKR_ERR_ORDER, VKR_ERR_NO_DEVICE = -1, -2, -3, -4, -5
 COVERAGE_FULLSCREEN = 0
 CUBE_LAYOUT_LINEAR, CUBE_LAYOUT_TILED_8X4 = 0, 1
+ENV_LAYOUT_LINEAR, ENV_LAYOUT_TILED_4X4 = 0, 1
 WRAP_REPEAT, WRAP_CLAMP = 0, 1
 SRC_RGBA8_SRGB, SRC_RGBA16F = 0, 1
 POST_SRGB_TARGET = 1
@@ -95,8 +96,9 @@ PROTOTYPES = {
     "vkr_postprocess": [_vp, _vp, _vp, _i32, _i32, _i32, _vp],
     "vkr_bloomv_postprocess": [C.POINTER(BloomPostArgs), _vp],
     "vkr_ibl_equirect_to_cube": [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp],
-    "vkr_ibl_irradiance": [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp],
-    "vkr_ibl_prefilter": [_vp, _i32, _vp, _i32, _f, _i32, _i32, _vp],
+    "vkr_ibl_irradiance": [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp],
+    "vkr_ibl_prefilter": [_vp, _i32, _i32, _vp, _i32, _f, _i32, _i32, _vp],
+    "vkr_tile_rgba16f_faces": [_vp, _vp, _i32, _i32, _vp],
     "vkr_ibl_brdf_lut": [_vp, _i32, _i32, _i32, _vp],
     "vkr_create": [C.POINTER(Config), C.POINTER(_vp)],
     "vkr_destroy": [_vp],

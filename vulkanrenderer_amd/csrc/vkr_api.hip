@@ -46,6 +46,7 @@ struct vkr_ctx {
     void *env = nullptr, *irradiance = nullptr, *brdf_lut = nullptr;
     std::vector<void *> prefilter;  // one image per mip
     bool have_env = false, have_irr = false, have_pref = false, have_lut = false;
+    void *env_tiled = nullptr;      // the environment cube as 4x4-texel tiles (what the IBL passes sample)
     float *cube_staging = nullptr;  // one linear depth cube on its way into the tiled storage
     bool cubes_tiled = false;       // point shadow cubes are stored VKR_CUBE_LAYOUT_TILED_8X4
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -94,7 +95,7 @@ static void destroy(vkr_ctx *c)
         if (f.cube_shadow) (void)hipFree(f.cube_shadow);
         if (f.lights) (void)hipFree(f.lights);
     }
-    void *ibl[] = {c->env, c->irradiance, c->brdf_lut, c->cube_staging};
+    void *ibl[] = {c->env, c->env_tiled, c->irradiance, c->brdf_lut, c->cube_staging};
     for (void *p : ibl) if (p) (void)hipFree(p);
     for (void *p : c->prefilter) if (p) (void)hipFree(p);
     for (hipEvent_t e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -208,6 +209,7 @@ extern "C" int32_t vkr_create(const VkrConfig *config, vkr_ctx **out)
         c->cubes_tiled = cfg.point_shadow_res % 8 == 0;
         if (c->cubes_tiled) VKR_HIP_CHECK(hipMalloc((void **)&c->cube_staging, (size_t)6 * cfg.point_shadow_res * cfg.point_shadow_res * 4));
         VKR_HIP_CHECK(hipMalloc(&c->env, cube_bytes(cfg.env_res)));
+        if (cfg.env_res % 4 == 0) VKR_HIP_CHECK(hipMalloc(&c->env_tiled, cube_bytes(cfg.env_res)));
         VKR_HIP_CHECK(hipMalloc(&c->irradiance, cube_bytes(cfg.irradiance_res)));
         VKR_HIP_CHECK(hipMalloc(&c->brdf_lut, (size_t)cfg.brdf_lut_res * cfg.brdf_lut_res * 4));
         for (int m = 0; m < cfg.prefilter_mips; m++) VKR_HIP_CHECK(hipMalloc(&c->prefilter[m], cube_bytes(cfg.prefilter_res >> m)));
@@ -336,6 +338,7 @@ extern "C" int32_t vkr_create_skybox_cubemap(vkr_ctx *c, const void *equirect, i
     VKR_HIP_CHECK(hipMalloc(&src, bytes));
     int32_t rc = upload(c, src, equirect, bytes);
     if (rc == VKR_OK) rc = vkr_ibl_equirect_to_cube(src, w, h, src_format, c->env, c->cfg.env_res, 0, 6 * c->cfg.env_res, c->stream);
+    if (rc == VKR_OK && c->env_tiled) rc = vkr_tile_rgba16f_faces(c->env, c->env_tiled, 6, c->cfg.env_res, c->stream);
     hipError_t e = hipStreamSynchronize(c->stream);  // the reference waits with QueueWaitIdle (VulkanRenderer.cs:714)
     (void)hipFree(src);
     if (rc != VKR_OK) return rc;
@@ -349,6 +352,10 @@ extern "C" int32_t vkr_upload_env_cube(vkr_ctx *c, const void *cube)
     VKR_CTX(c);
     VKR_REQUIRE(cube != nullptr, "vkr_upload_env_cube: cube is null");
     int32_t rc = upload(c, c->env, cube, cube_bytes(c->cfg.env_res));
+    if (rc == VKR_OK && c->env_tiled) {
+        rc = vkr_tile_rgba16f_faces(c->env, c->env_tiled, 6, c->cfg.env_res, c->stream);
+        if (rc == VKR_OK) VKR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
     if (rc == VKR_OK) c->have_env = true;
     return rc;
 }
@@ -357,7 +364,9 @@ extern "C" int32_t vkr_create_irradiance_cubemap(vkr_ctx *c, int32_t order)
 {
     VKR_CTX(c);
     if (!c->have_env) return fail(VKR_ERR_ORDER, "vkr_create_irradiance_cubemap: no environment cube yet");
-    int32_t rc = vkr_ibl_irradiance(c->env, c->cfg.env_res, c->irradiance, c->cfg.irradiance_res, order, 0, 6 * c->cfg.irradiance_res, c->stream);
+    const void *env = c->env_tiled ? c->env_tiled : c->env;
+    const int32_t layout = c->env_tiled ? VKR_ENV_LAYOUT_TILED_4X4 : VKR_ENV_LAYOUT_LINEAR;
+    int32_t rc = vkr_ibl_irradiance(env, c->cfg.env_res, layout, c->irradiance, c->cfg.irradiance_res, order, 0, 6 * c->cfg.irradiance_res, c->stream);
     if (rc != VKR_OK) return rc;
     VKR_HIP_CHECK(hipStreamSynchronize(c->stream));
     c->have_irr = true;
@@ -368,11 +377,13 @@ extern "C" int32_t vkr_create_prefiltered_cubemap(vkr_ctx *c)
 {
     VKR_CTX(c);
     if (!c->have_env) return fail(VKR_ERR_ORDER, "vkr_create_prefiltered_cubemap: no environment cube yet");
+    const void *env = c->env_tiled ? c->env_tiled : c->env;
+    const int32_t layout = c->env_tiled ? VKR_ENV_LAYOUT_TILED_4X4 : VKR_ENV_LAYOUT_LINEAR;
     for (int m = 0; m < c->cfg.prefilter_mips; m++) {
         // VulkanRenderer.cs:874: roughness = mip / (mips - 1)
         float rough = c->cfg.prefilter_mips > 1 ? (float)m / (float)(c->cfg.prefilter_mips - 1) : 0.0f;
         int n = c->cfg.prefilter_res >> m;
-        int32_t rc = vkr_ibl_prefilter(c->env, c->cfg.env_res, c->prefilter[m], n, rough, 0, 6 * n, c->stream);
+        int32_t rc = vkr_ibl_prefilter(env, c->cfg.env_res, layout, c->prefilter[m], n, rough, 0, 6 * n, c->stream);
         if (rc != VKR_OK) return rc;
     }
     VKR_HIP_CHECK(hipStreamSynchronize(c->stream));

@@ -144,7 +144,18 @@ VKR_DEV bool cube_fold(int n, int f, int i, int j, int &of, int &oi, int &oj)
     return true;
 }
 
+// Index of texel (i, j) of face f in an RGBA16F cube of face size n.  Row-major, or (TILED)
+// 4x4-texel tiles of 128 bytes stored row-major by tile (n % 4 == 0): the 2x2 footprint of a
+// bilinear lookup then lies in one cache line 9 times out of 16 instead of never.
+template <bool TILED> VKR_DEV size_t cube_texel_index(int n, int f, int i, int j)
+{
+    const size_t face0 = (size_t)f * n * n;
+    if (!TILED) return face0 + (size_t)j * n + i;
+    return face0 + (((unsigned)j >> 2) * ((unsigned)n >> 2) + ((unsigned)i >> 2)) * 16u + ((unsigned)j & 3u) * 4u + ((unsigned)i & 3u);
+}
+
 // LINEAR, seamless lookup in an RGBA16F cube, mip 0 (textureSampler on a one-level cube view)
+template <bool TILED = false>
 VKR_DEV f3 texcube_rgb_linear(const void *cube, int n, f3 r)
 {
     int face; float s, t;
@@ -157,8 +168,16 @@ VKR_DEV f3 texcube_rgb_linear(const void *cube, int n, f3 r)
     const uint2 *base = (const uint2 *)cube;
     rgba t0, t1, t2, t3;
     if (i0 >= 0 && j0 >= 0 && i0 + 1 < n && j0 + 1 < n) {  // all four taps on this face
-        const uint2 *p = base + ((size_t)face * n + j0) * n + i0;
-        t0 = unpack4(p[0]); t1 = unpack4(p[1]); t2 = unpack4(p[n]); t3 = unpack4(p[n + 1]);
+        if (!TILED) {
+            const uint2 *p = base + ((size_t)face * n + j0) * n + i0;
+            t0 = unpack4(p[0]); t1 = unpack4(p[1]); t2 = unpack4(p[n]); t3 = unpack4(p[n + 1]);
+        } else {
+            const uint2 *fb = base + (size_t)face * n * n;
+            const unsigned tiles4 = (unsigned)n * 4u;  // texels in one row of tiles
+            const unsigned c0 = ((unsigned)i0 >> 2) * 16u + ((unsigned)i0 & 3u), c1 = ((unsigned)(i0 + 1) >> 2) * 16u + ((unsigned)(i0 + 1) & 3u);
+            const unsigned r0 = ((unsigned)j0 >> 2) * tiles4 + ((unsigned)j0 & 3u) * 4u, r1 = ((unsigned)(j0 + 1) >> 2) * tiles4 + ((unsigned)(j0 + 1) & 3u) * 4u;
+            t0 = unpack4(fb[r0 + c0]); t1 = unpack4(fb[r0 + c1]); t2 = unpack4(fb[r1 + c0]); t3 = unpack4(fb[r1 + c1]);
+        }
     } else {
         rgba tx[4];
         bool ok[4];
@@ -167,7 +186,7 @@ VKR_DEV f3 texcube_rgb_linear(const void *cube, int n, f3 r)
         for (int k = 0; k < 4; k++) {
             int of, oi, oj;
             ok[k] = cube_fold(n, face, i0 + (k & 1), j0 + (k >> 1), of, oi, oj);
-            if (ok[k]) { tx[k] = unpack4(base[((size_t)of * n + oj) * n + oi]); nok++; }
+            if (ok[k]) { tx[k] = unpack4(base[cube_texel_index<TILED>(n, of, oi, oj)]); nok++; }
             else { tx[k].r = tx[k].g = tx[k].b = tx[k].a = 0.0f; }
         }
         if (nok == 3) {  // cube corner: the missing texel is the mean of the other three

@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256) void equirect_kernel(const void *src, int sw, 
 // one slice) into LDS; one lane per colour channel then adds the chunk to the running sum in
 // sample order while the other waves already produce the next chunk into the second buffer.
 static constexpr int IRR_CHUNK_SLICES = 16;
+template <bool TILED>
 __global__ __launch_bounds__(256) void irradiance_texel_kernel(const void *env, int env_n, uint2 *out, int n, int nphi, int ntheta, int row_begin)
 {
     __shared__ float term[2][3][IRR_CHUNK_SLICES * IRR_MAX_THETA];
@@ -132,18 +133,35 @@ __global__ __launch_bounds__(256) void irradiance_texel_kernel(const void *env, 
                 const f3 sv = mk3(fma_(tz, N.x, fma_(ty, up.x, tx * right.x)),
                                   fma_(tz, N.y, fma_(ty, up.y, tx * right.y)),
                                   fma_(tz, N.z, fma_(ty, up.z, tx * right.z)));
-                const f3 c = texcube_rgb_linear(env, env_n, sv);
+                const f3 c = texcube_rgb_linear<TILED>(env, env_n, sv);
                 const int p = al * ntheta + b;
                 buf[0][p] = c.x * ct; buf[1][p] = c.y * ct; buf[2][p] = c.z * ct;
             }
         }
         __syncthreads();
         if (tid < 3) {
-            const int slices = min(IRR_CHUNK_SLICES, nphi - a0);
+            // the running sum is one dependent fma per term; the terms are read eight ahead so
+            // that a step costs the fma's latency, not an LDS round trip
+            const int terms = min(IRR_CHUNK_SLICES, nphi - a0) * ntheta;
             const float *mine = buf[tid];
-            for (int al = 0; al < slices; al++) {
-                for (int bb = 0; bb < ntheta; bb++) acc = fma_(mine[bb], sin_theta[bb], acc);
-                mine += ntheta;
+            int q = 0, bb = 0;
+            for (; q + 8 <= terms; q += 8) {
+                float v[8], st8[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    v[u] = mine[q + u];
+                    int t = bb + u;
+                    t = t >= ntheta ? t - ntheta : t;
+                    st8[u] = sin_theta[t];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) acc = fma_(v[u], st8[u], acc);
+                bb += 8;
+                bb = bb >= ntheta ? bb - ntheta : bb;
+            }
+            for (; q < terms; q++) {
+                acc = fma_(mine[q], sin_theta[bb], acc);
+                bb = bb + 1 == ntheta ? 0 : bb + 1;
             }
         }
     }
@@ -158,6 +176,7 @@ __global__ __launch_bounds__(256) void irradiance_texel_kernel(const void *env, 
 // Phi-slice order, one workgroup per output texel: lane a owns phi slice a (252 of the 256 lanes),
 // sums its 63 theta samples from zero, and the slice sums are then added in phi order by one lane
 // per colour channel.
+template <bool TILED>
 __global__ __launch_bounds__(256) void irradiance_slices_kernel(const void *env, int env_n, uint2 *out, int n, int nphi, int ntheta, int row_begin)
 {
     __shared__ float part[3][IRR_MAX_PHI];
@@ -178,7 +197,7 @@ __global__ __launch_bounds__(256) void irradiance_slices_kernel(const void *env,
             const f3 sv = mk3(fma_(tz, N.x, fma_(ty, up.x, tx * right.x)),
                               fma_(tz, N.y, fma_(ty, up.y, tx * right.y)),
                               fma_(tz, N.z, fma_(ty, up.z, tx * right.z)));
-            const f3 c = texcube_rgb_linear(env, env_n, sv);
+            const f3 c = texcube_rgb_linear<TILED>(env, env_n, sv);
             pr = fma_(c.x * ct, st, pr);
             pg = fma_(c.y * ct, st, pg);
             pb = fma_(c.z * ct, st, pb);
@@ -219,6 +238,7 @@ VKR_DEV float2 ggx_theta(int s, float rough)
 // prefilter.frag:21-63, one workgroup per output texel.  Every lane evaluates four of the 1024
 // samples (environment colour and N.L) into LDS; four lanes -- red, green, blue and the weight
 // total -- then add them up in sample order, which is the shader's single running sum.
+template <bool TILED>
 __global__ __launch_bounds__(256) void prefilter_texel_kernel(const void *env, int env_n, uint2 *out, int n, float rough, int row_begin)
 {
     __shared__ __align__(16) float term[4][SAMPLE_COUNT];  // [0..2] environment colour, [3] N.L
@@ -244,7 +264,7 @@ __global__ __launch_bounds__(256) void prefilter_texel_kernel(const void *env, i
         const f3 L = normalize3_fast(mk3(fma_(vh2, H.x, -N.x), fma_(vh2, H.y, -N.y), fma_(vh2, H.z, -N.z)));
         const float NdotL = max0(dot3(N, L));
         f3 c = mk3(0.0f, 0.0f, 0.0f);
-        if (NdotL > 0.0f) c = texcube_rgb_linear(env, env_n, L);  // the shader's mip level is clamped to 0 by the sampler
+        if (NdotL > 0.0f) c = texcube_rgb_linear<TILED>(env, env_n, L);  // the shader's mip level is clamped to 0 by the sampler
         term[0][s] = c.x; term[1][s] = c.y; term[2][s] = c.z; term[3][s] = NdotL;
     }
     __syncthreads();
@@ -310,6 +330,28 @@ __global__ __launch_bounds__(256) void brdf_lut_kernel(uint32_t *out, int n, int
     out[(size_t)row * n + i] = __builtin_bit_cast(uint32_t, o);
 }
 
+// Row-major RGBA16F faces -> 4x4-texel tiles.  One lane moves one 32-byte tile row; eight lanes
+// write two consecutive tiles (256 contiguous bytes).
+__global__ __launch_bounds__(256) void tile_rgba16f_kernel(const uint4 *src, uint4 *dst, int n, unsigned tiles_per_face, unsigned total_tiles)
+{
+    const unsigned g = blockIdx.x * 256u + threadIdx.x;
+    const unsigned t = g >> 2, row = g & 3u;  // tile over all faces, row inside the tile
+    if (t >= total_tiles) return;
+    const unsigned face = t / tiles_per_face, tf = t - face * tiles_per_face;
+    const unsigned tiles_x = (unsigned)n >> 2;
+    const unsigned ty = tf / tiles_x, tx = tf - ty * tiles_x;
+    const size_t texel = (size_t)face * n * n + (size_t)(ty * 4u + row) * n + tx * 4u;  // four texels = two uint4
+    dst[(size_t)g * 2u] = src[texel >> 1];
+    dst[(size_t)g * 2u + 1u] = src[(texel >> 1) + 1u];
+}
+
+static int32_t check_env_layout(const char *who, int env_n, int layout)
+{
+    VKR_REQUIRE(layout == VKR_ENV_LAYOUT_LINEAR || layout == VKR_ENV_LAYOUT_TILED_4X4, "%s: unknown environment layout %d", who, layout);
+    VKR_REQUIRE(layout == VKR_ENV_LAYOUT_LINEAR || env_n % 4 == 0, "%s: the tiled environment layout needs a face size that is a multiple of 4 (got %d)", who, env_n);
+    return VKR_OK;
+}
+
 static int32_t check_rows(const char *who, int n, int total_rows, int row_begin, int row_end)
 {
     VKR_REQUIRE(n > 0, "%s: bad size %d", who, n);
@@ -335,36 +377,56 @@ extern "C" int32_t vkr_ibl_equirect_to_cube(const void *src, int32_t src_w, int3
     return launch_status("vkr_ibl_equirect_to_cube");
 }
 
-extern "C" int32_t vkr_ibl_irradiance(const void *env, int32_t env_n, void *out, int32_t n, int32_t order, int32_t row_begin, int32_t row_end, void *stream)
+extern "C" int32_t vkr_tile_rgba16f_faces(const void *linear, void *tiled, int32_t n_faces, int32_t n, void *stream)
+{
+    using namespace vkr;
+    VKR_REQUIRE(linear && tiled, "vkr_tile_rgba16f_faces: an image is null");
+    VKR_REQUIRE(n_faces >= 0 && n > 0 && n % 4 == 0 && n <= 16384, "vkr_tile_rgba16f_faces: %d faces of size %d (size must be a multiple of 4, at most 16384)", n_faces, n);
+    const size_t bytes = (size_t)n_faces * n * n * 8;
+    const char *a = (const char *)linear, *b = (const char *)tiled;
+    VKR_REQUIRE(a + bytes <= b || b + bytes <= a, "vkr_tile_rgba16f_faces: source and destination overlap");
+    const uint64_t tiles_per_face = (uint64_t)(n / 4) * (n / 4), total = tiles_per_face * (uint64_t)n_faces;
+    VKR_REQUIRE(total < (1ull << 29), "vkr_tile_rgba16f_faces: too many texels for one call");
+    if (total == 0) return VKR_OK;
+    hipLaunchKernelGGL(tile_rgba16f_kernel, dim3((unsigned)((total * 4 + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       (const uint4 *)linear, (uint4 *)tiled, n, (unsigned)tiles_per_face, (unsigned)total);
+    return launch_status("vkr_tile_rgba16f_faces");
+}
+
+extern "C" int32_t vkr_ibl_irradiance(const void *env, int32_t env_n, int32_t env_layout, void *out, int32_t n, int32_t order, int32_t row_begin, int32_t row_end, void *stream)
 {
     using namespace vkr;
     VKR_REQUIRE(env && out && env_n > 0, "vkr_ibl_irradiance: an image is null or env size is bad");
     VKR_REQUIRE(order == VKR_IRRADIANCE_SEQUENTIAL || order == VKR_IRRADIANCE_PHI_SLICES, "vkr_ibl_irradiance: unknown summation order %d", order);
     int32_t rc = check_rows("vkr_ibl_irradiance", n, 6 * n, row_begin, row_end);
     if (rc != VKR_OK) return rc;
+    if ((rc = check_env_layout("vkr_ibl_irradiance", env_n, env_layout)) != VKR_OK) return rc;
+    const bool tiled = env_layout == VKR_ENV_LAYOUT_TILED_4X4;
     if ((rc = ensure_tables()) != VKR_OK) return rc;
     if (row_end == row_begin) return VKR_OK;
     if (order == VKR_IRRADIANCE_PHI_SLICES) {
         dim3 grid(n, row_end - row_begin);
-        hipLaunchKernelGGL(irradiance_slices_kernel, grid, dim3(256), 0, as_stream(stream), env, env_n, (uint2 *)out, n, g_irr_nphi, g_irr_ntheta, row_begin);
+        hipLaunchKernelGGL(tiled ? irradiance_slices_kernel<true> : irradiance_slices_kernel<false>, grid, dim3(256), 0, as_stream(stream), env, env_n, (uint2 *)out, n, g_irr_nphi, g_irr_ntheta, row_begin);
     } else {
         dim3 grid(n, row_end - row_begin);
-        hipLaunchKernelGGL(irradiance_texel_kernel, grid, dim3(256), 0, as_stream(stream), env, env_n, (uint2 *)out, n, g_irr_nphi, g_irr_ntheta, row_begin);
+        hipLaunchKernelGGL(tiled ? irradiance_texel_kernel<true> : irradiance_texel_kernel<false>, grid, dim3(256), 0, as_stream(stream), env, env_n, (uint2 *)out, n, g_irr_nphi, g_irr_ntheta, row_begin);
     }
     return launch_status("vkr_ibl_irradiance");
 }
 
-extern "C" int32_t vkr_ibl_prefilter(const void *env, int32_t env_n, void *out, int32_t n, float roughness, int32_t row_begin, int32_t row_end, void *stream)
+extern "C" int32_t vkr_ibl_prefilter(const void *env, int32_t env_n, int32_t env_layout, void *out, int32_t n, float roughness, int32_t row_begin, int32_t row_end, void *stream)
 {
     using namespace vkr;
     VKR_REQUIRE(env && out && env_n > 0, "vkr_ibl_prefilter: an image is null or env size is bad");
     VKR_REQUIRE(roughness >= 0.0f && roughness <= 1.0f, "vkr_ibl_prefilter: roughness %g outside [0,1]", (double)roughness);
     int32_t rc = check_rows("vkr_ibl_prefilter", n, 6 * n, row_begin, row_end);
     if (rc != VKR_OK) return rc;
+    if ((rc = check_env_layout("vkr_ibl_prefilter", env_n, env_layout)) != VKR_OK) return rc;
+    const bool tiled = env_layout == VKR_ENV_LAYOUT_TILED_4X4;
     if ((rc = ensure_tables()) != VKR_OK) return rc;
     if (row_end == row_begin) return VKR_OK;
     dim3 grid(n, row_end - row_begin);
-    hipLaunchKernelGGL(prefilter_texel_kernel, grid, dim3(256), 0, as_stream(stream), env, env_n, (uint2 *)out, n, roughness, row_begin);
+    hipLaunchKernelGGL(tiled ? prefilter_texel_kernel<true> : prefilter_texel_kernel<false>, grid, dim3(256), 0, as_stream(stream), env, env_n, (uint2 *)out, n, roughness, row_begin);
     return launch_status("vkr_ibl_prefilter");
 }
 

@@ -51,11 +51,17 @@ class HipIblBackend:
     def equirect(self, src, src_format, env):
         self.P.equirect_to_cube(src, src_format, env)
 
-    def irradiance(self, env, out, rows):
-        self.P.irradiance(env, out, _lib.IRRADIANCE_SEQUENTIAL, rows=rows)
+    def sampling_copy(self, env):
+        """The cube the irradiance / prefilter passes read: 4x4-texel tiles when the face size allows."""
+        if env.shape[1] % 4 == 0:
+            return self.P.tile_env_cube(env), _lib.ENV_LAYOUT_TILED_4X4
+        return env, _lib.ENV_LAYOUT_LINEAR
 
-    def prefilter(self, env, out, roughness, rows):
-        self.P.prefilter(env, out, roughness, rows=rows)
+    def irradiance(self, env, out, rows, env_layout=_lib.ENV_LAYOUT_LINEAR):
+        self.P.irradiance(env, out, _lib.IRRADIANCE_SEQUENTIAL, rows=rows, env_layout=env_layout)
+
+    def prefilter(self, env, out, roughness, rows, env_layout=_lib.ENV_LAYOUT_LINEAR):
+        self.P.prefilter(env, out, roughness, rows=rows, env_layout=env_layout)
 
     def brdf_lut(self, out, rows):
         self.P.brdf_lut(out, rows=rows)
@@ -84,11 +90,12 @@ class IblPrecompute:
         cfg, be = self.cfg, self.backend
         env = be.empty((6, cfg.env_res, cfg.env_res, 4), torch.float16)
         be.equirect(src, src_format, env)  # replicated
+        sampled, layout = be.sampling_copy(env)
 
         n = cfg.irradiance_res
         irr_flat, irr = self._padded_cube(n)
         r0, r1, per = row_share(6 * n, self.rank, self.world)
-        be.irradiance(env, irr, (r0, r1))
+        be.irradiance(sampled, irr, (r0, r1), layout)
         self._all_gather_rows(irr_flat, per)
 
         mips = []
@@ -96,7 +103,7 @@ class IblPrecompute:
             n = cfg.prefilter_res >> m
             flat, cube = self._padded_cube(n)
             r0, r1, per = row_share(6 * n, self.rank, self.world)
-            be.prefilter(env, cube, m / max(cfg.prefilter_mips - 1, 1), (r0, r1))
+            be.prefilter(sampled, cube, m / max(cfg.prefilter_mips - 1, 1), (r0, r1), layout)
             self._all_gather_rows(flat, per)
             mips.append(cube)
 

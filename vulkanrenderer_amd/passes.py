@@ -162,18 +162,28 @@ def equirect_to_cube(src: torch.Tensor, src_format: int, cube: torch.Tensor, row
     _lib.check(lib.vkr_ibl_equirect_to_cube(_ptr(src), src.shape[1], src.shape[0], src_format, _ptr(cube), n, r0, r1, _stream()))
 
 
-def irradiance(env: torch.Tensor, out: torch.Tensor, order: int = _lib.IRRADIANCE_SEQUENTIAL, rows=None) -> None:
+def tile_env_cube(linear: torch.Tensor) -> torch.Tensor:
+    """[6, n, n, 4] float16 cube, row-major -> the same cube as 4x4-texel tiles (new tensor, same shape)."""
+    lib = _lib.load()
+    out = torch.empty_like(linear)
+    _lib.check(lib.vkr_tile_rgba16f_faces(_ptr(linear), _ptr(out), linear.shape[0], linear.shape[1], _stream()))
+    return out
+
+
+def irradiance(env: torch.Tensor, out: torch.Tensor, order: int = _lib.IRRADIANCE_SEQUENTIAL, rows=None,
+               env_layout: int = _lib.ENV_LAYOUT_LINEAR) -> None:
     lib = _lib.load()
     n = out.shape[1]
     r0, r1 = _rows(6 * n, rows)
-    _lib.check(lib.vkr_ibl_irradiance(_ptr(env), env.shape[1], _ptr(out), n, order, r0, r1, _stream()))
+    _lib.check(lib.vkr_ibl_irradiance(_ptr(env), env.shape[1], env_layout, _ptr(out), n, order, r0, r1, _stream()))
 
 
-def prefilter(env: torch.Tensor, out: torch.Tensor, roughness: float, rows=None) -> None:
+def prefilter(env: torch.Tensor, out: torch.Tensor, roughness: float, rows=None,
+              env_layout: int = _lib.ENV_LAYOUT_LINEAR) -> None:
     lib = _lib.load()
     n = out.shape[1]
     r0, r1 = _rows(6 * n, rows)
-    _lib.check(lib.vkr_ibl_prefilter(_ptr(env), env.shape[1], _ptr(out), n, C.c_float(roughness), r0, r1, _stream()))
+    _lib.check(lib.vkr_ibl_prefilter(_ptr(env), env.shape[1], env_layout, _ptr(out), n, C.c_float(roughness), r0, r1, _stream()))
 
 
 def brdf_lut(out: torch.Tensor, rows=None) -> None:
