@@ -273,6 +273,14 @@ def main() -> None:
                       "ms_per_step + this = a frame whose shadow pass hands over row-major maps")
         rt["value_with_retile_every_frame"] = round(px / ((ms_per_step + rt["ms"]) * 1e-3) / 1e6, 3)
         out["shadow_retile"] = rt
+    if world == 1:
+        import ctypes
+        fp32, copy = ctypes.c_float(), ctypes.c_float()
+        _lib.check(_lib.load().vkr_measure_peaks(ctypes.byref(fp32), ctypes.byref(copy)))
+        out["measured_peaks"] = {"fp32_fma_loop_tflops": round(fp32.value, 1), "copy_1GiB_GBps": round(copy.value, 1),
+                                 "shade_frac_of_measured": round(shade_tflops / fp32.value, 4),
+                                 "bloom_h_frac_of_measured": round(16 * px / (kernel_ms["bloom_h"] * 1e-3) / 1e9 / copy.value, 4),
+                                 "bloom_v_frac_of_measured": round(20 * px / (kernel_ms["bloomv_post"] * 1e-3) / 1e9 / copy.value, 4)}
     if not args.no_ibl:
         out["ibl_precompute"] = time_ibl(device)
     if world == 1 and args.cpu_rows > 0:

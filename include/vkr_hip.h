@@ -261,6 +261,11 @@ VKR_EXPORT int32_t vkr_get_timing(vkr_ctx *ctx, VkrTiming *out);
  * for sqrt.  No counterpart in the reference: it backs the bit-exactness claim of the kernels. */
 VKR_EXPORT int32_t vkr_selftest_math(uint64_t *counts7);
 
+/* Measures, on the current device, the FP32 vector rate of an fma loop (TFLOP/s) and the rate of a
+ * 1 GiB device-to-device copy (GB/s, bytes read + bytes written): the peaks a kernel on this
+ * machine can actually reach, to set beside the nominal ones.  Allocates 2 GiB for the call. */
+VKR_EXPORT int32_t vkr_measure_peaks(float *fp32_tflops, float *copy_gbs);
+
 #ifdef __cplusplus
 }
 #endif

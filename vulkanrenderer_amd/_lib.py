@@ -99,6 +99,7 @@ PROTOTYPES = {
     "vkr_ibl_irradiance": [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp],
     "vkr_ibl_prefilter": [_vp, _i32, _i32, _vp, _i32, _f, _i32, _i32, _vp],
     "vkr_tile_rgba16f_faces": [_vp, _vp, _i32, _i32, _vp],
+    "vkr_measure_peaks": [C.POINTER(C.c_float), C.POINTER(C.c_float)],
     "vkr_ibl_brdf_lut": [_vp, _i32, _i32, _i32, _vp],
     "vkr_create": [C.POINTER(Config), C.POINTER(_vp)],
     "vkr_destroy": [_vp],

@@ -36,7 +36,76 @@ __global__ __launch_bounds__(256) void selftest_math_kernel(unsigned long long *
         if (local[k]) atomicAdd(&counts[k], local[k]);
 }
 
+// 8 independent fma chains per lane, 4096 fmas each: the FP32 vector rate a kernel can reach.
+__global__ __launch_bounds__(256) void peak_fma_kernel(float *out, float a, float b)
+{
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = (float)(threadIdx.x + k);
+    for (int it = 0; it < 4096; it++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = __builtin_fmaf(v[k], a, b);
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) s += v[k];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+// 16 bytes per lane in, 16 out
+__global__ __launch_bounds__(256) void peak_copy_kernel(const uint4 *src, uint4 *dst, size_t n)
+{
+    // four independent 16-byte loads per lane before the first store
+    const size_t i = ((size_t)blockIdx.x * 256 * 4) + threadIdx.x;
+    if (i + 3 * 256 < n) {
+        const uint4 a = src[i], b = src[i + 256], c = src[i + 512], d = src[i + 768];
+        dst[i] = a; dst[i + 256] = b; dst[i + 512] = c; dst[i + 768] = d;
+    }
+}
+
 }  // namespace vkr
+
+extern "C" int32_t vkr_measure_peaks(float *fp32_tflops, float *copy_gbs)
+{
+    using namespace vkr;
+    VKR_REQUIRE(fp32_tflops && copy_gbs, "vkr_measure_peaks: an output is null");
+    const size_t copy_bytes = (size_t)1 << 30;  // 1 GiB each way: well past the 256 MiB last-level cache
+    const int fma_blocks = 256 * 16;
+    void *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int32_t rc = VKR_OK;
+    auto body = [&]() -> int32_t {
+        VKR_HIP_CHECK(hipMalloc(&a, copy_bytes));
+        VKR_HIP_CHECK(hipMalloc(&b, copy_bytes));
+        VKR_HIP_CHECK(hipMemset(a, 1, copy_bytes));
+        VKR_HIP_CHECK(hipEventCreate(&e0));
+        VKR_HIP_CHECK(hipEventCreate(&e1));
+        float ms = 0.0f;
+        for (int pass = 0; pass < 2; pass++) {  // the first pass warms up
+            VKR_HIP_CHECK(hipEventRecord(e0, nullptr));
+            hipLaunchKernelGGL(peak_fma_kernel, dim3(fma_blocks), dim3(256), 0, nullptr, (float *)b, 0.999f, 0.001f);
+            VKR_HIP_CHECK(hipEventRecord(e1, nullptr));
+            VKR_HIP_CHECK(hipEventSynchronize(e1));
+            VKR_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        }
+        *fp32_tflops = (float)((double)fma_blocks * 256 * 8 * 4096 * 2 / (ms * 1e-3) / 1e12);
+        for (int pass = 0; pass < 2; pass++) {
+            VKR_HIP_CHECK(hipEventRecord(e0, nullptr));
+            hipLaunchKernelGGL(peak_copy_kernel, dim3((unsigned)(copy_bytes / 16 / 1024)), dim3(256), 0, nullptr, (const uint4 *)a, (uint4 *)b, copy_bytes / 16);
+            VKR_HIP_CHECK(hipEventRecord(e1, nullptr));
+            VKR_HIP_CHECK(hipEventSynchronize(e1));
+            VKR_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        }
+        *copy_gbs = (float)(2.0 * (double)copy_bytes / (ms * 1e-3) / 1e9);
+        return launch_status("vkr_measure_peaks");
+    };
+    rc = body();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    return rc;
+}
 
 extern "C" int32_t vkr_selftest_math(uint64_t *counts7)
 {
