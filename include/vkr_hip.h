@@ -67,7 +67,8 @@ typedef struct VkrLightInfo {
 /* Which pixels a point light's draw touches (the reference rasterises a sphere mesh per light,
  * GraphicsPipeline.cs:100-117).  Only FULLSCREEN is implemented: it equals the reference
  * whenever the camera is inside every light volume. */
-#define VKR_COVERAGE_FULLSCREEN 0
+#define VKR_COVERAGE_FULLSCREEN 0 /* every light volume covers every pixel (exact while the camera is inside every volume) */
+#define VKR_COVERAGE_MESH 1       /* per-pixel coverage of the light-volume mesh, from vkr_light_coverage() */
 
 /* Memory layout of the D32F point-shadow cubes (the reference keeps them in OPTIMAL-tiled Vulkan
  * images, VulkanRenderer.cs:1348-1370, whose layout is the driver's; here it is explicit). */
@@ -110,7 +111,9 @@ typedef struct VkrShadeArgs {
     VkrSceneInfo scene;
     const VkrLightInfo *lights;                   /* device memory, n_lights entries */
     int32_t n_lights;
-    int32_t coverage_mode;
+    int32_t coverage_mode;                        /* VKR_COVERAGE_* */
+    const uint64_t *coverage_masks;               /* VKR_COVERAGE_MESH: masks written by vkr_light_coverage() for
+                                                     this strip (n_lights * ceil(rows/8) * ceil(width/8)) */
     const float *dir_shadow;  int32_t dir_res;    /* D32F dir_res^2 */
     const float *cube_shadow; int32_t cube_res;   /* D32F n_lights * 6 * cube_res^2 */
     int32_t cube_layout;                          /* VKR_CUBE_LAYOUT_* of cube_shadow */
@@ -120,6 +123,26 @@ typedef struct VkrShadeArgs {
     void *out_color, *out_threshold;              /* RGBA16F, rows*width texels each */
 } VkrShadeArgs;
 VKR_EXPORT int32_t vkr_shade(const VkrShadeArgs *args, void *stream);
+
+/* Which pixels the light.frag draw of each light touches: the light-volume mesh (the reference's
+ * unit sphere, assets/models/sphere/sphere.glb, or any closed mesh) is placed by each light's model
+ * matrix (Light.cs:10-26), transformed as light.vert:26 does, and its back faces are rasterised
+ * (FRONT faces culled, CCW front, no depth test: GraphicsPipeline.cs:100-117; depth clip 0 <= z <= w).
+ * Output: one 64-bit mask per (light, 8x8-pixel tile of the strip), bit (y&7)*8 + (x&7), tiles
+ * row-major, lights outermost -- the form VkrShadeArgs.coverage_masks takes. */
+typedef struct VkrCoverageArgs {
+    int32_t width, rows;          /* the image: a strip of the frame */
+    int32_t frame_rows, row0;     /* rows of the whole frame; the strip's first row in it */
+    VkrSceneInfo scene;           /* camera_view and camera_projection are read */
+    const VkrLightInfo *lights;   /* device memory; model matrices are read */
+    int32_t n_lights;
+    const float *verts;           /* device memory, 3 floats per vertex, at most 1024 vertices */
+    int32_t n_verts;
+    const uint32_t *indices;      /* device memory, 3 per triangle, counter-clockwise seen from outside */
+    int32_t n_tris;
+    uint64_t *masks;              /* device memory, n_lights * ceil(rows/8) * ceil(width/8) */
+} VkrCoverageArgs;
+VKR_EXPORT int32_t vkr_light_coverage(const VkrCoverageArgs *args, void *stream);
 
 /* Re-lays `n_faces` D32F faces of `res`^2 texels from VKR_CUBE_LAYOUT_LINEAR to
  * VKR_CUBE_LAYOUT_TILED_8X4 (res % 8 == 0; src and dst must not overlap).  No counterpart in the

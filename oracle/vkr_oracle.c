@@ -332,6 +332,9 @@ typedef struct {
     const uint16_t *prefilter; int32_t pref_res;      /* RGBA16F 6 * pref_res^2 (mip 0) */
     const uint16_t *brdf_lut; int32_t lut_res;        /* RG16F lut_res^2 */
     uint16_t *out_color, *out_threshold;              /* RGBA16F */
+    const uint64_t *coverage;                         /* NULL: every light volume covers every pixel;
+                                                         else one 64-bit mask per (light, 8x8-pixel tile),
+                                                         see orc_light_coverage */
 } orc_shade_args;
 
 typedef struct {
@@ -496,8 +499,14 @@ static void shade_pixel(const orc_shade_args *a, size_t p, int first_light, int 
 
     /* one additive draw per light, in list order; the attachment is RGBA16F so the running sum
      * is rounded to binary16 after every draw (GraphicsPipelineBuilder.cs:157-187) */
+    const int px_x = (int)(p % (size_t)a->width), px_y = (int)(p / (size_t)a->width);
+    const int tiles_x = (a->width + 7) / 8, tiles_y = (a->height + 7) / 8;
     for (int li = first_light; li < last_light; li++) {
         const orc_light_info *lt = a->lights + li;
+        if (a->coverage) { /* the draw touches only the pixels its light volume covers (light.vert, Light.cs:20-26) */
+            uint64_t m = a->coverage[((size_t)li * tiles_y + px_y / 8) * tiles_x + px_x / 8];
+            if (!((m >> ((px_y & 7) * 8 + (px_x & 7))) & 1)) continue;
+        }
         v3 lp = v3_(lt->position[0], lt->position[1], lt->position[2]);
         v3 out = v3_(0, 0, 0);
         /* A cleared G-buffer texel has normal (0,0,0); normalize() of it is NaN and the shader's
@@ -542,6 +551,140 @@ ORC_API void orc_shade(const orc_shade_args *a, int row_begin, int row_end)
     for (int y = row_begin; y < row_end; y++)
         for (int x = 0; x < a->width; x++)
             shade_pixel(a, (size_t)y * a->width + x, 0, a->n_lights, 1);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Light-volume coverage.  The reference draws, per light, a sphere mesh scaled to the light's
+ * reach and moved to its position (Light.cs:10-26), transformed by light.vert:26
+ * (proj * view * model * vec4(pos, 1)), with FRONT faces culled, CCW front, no depth test
+ * (GraphicsPipeline.cs:100-117) and the default depth clip 0 <= z <= w.  light.frag then runs on
+ * the pixels the remaining (back-facing) triangles cover.  Which pixels those are is decided by
+ * the rasteriser of the Vulkan implementation, not by any reference file; restated here from the
+ * specification's definition (a pixel belongs to a triangle when its centre lies inside the
+ * projected triangle) in homogeneous form, so that triangles crossing the eye plane need no
+ * clipping:
+ *   with V0,V1,V2 the clip-space (x,y,w) of the corners and p = (xn, yn, 1) the pixel centre in
+ *   normalised device coordinates, E0 = p.(V1xV2), E1 = p.(V2xV0), E2 = p.(V0xV1) and
+ *   D = V0.(V1xV2).  D > 0 is a back face (the y-flipped projection of Camera.cs:30-35 with
+ *   FrontFace.CounterClockwise makes D < 0 front); the centre is inside, in front of the eye,
+ *   when E0,E1,E2 >= 0 and E0+E1+E2 > 0; its depth passes the clip when 0 <= sum(Ei*zi) <= D.
+ * All of it is evaluated in binary64 from the binary32 clip coordinates with a fixed operation
+ * order, edges closed on both sides (two triangles sharing an edge compute exactly negated edge
+ * functions, so a centre on the edge belongs to both and the union has no holes).
+ * Output: one 64-bit mask per (light, 8x8-pixel tile): bit (y&7)*8 + (x&7). */
+
+typedef struct {
+    int32_t width, rows;        /* the image (a strip of the frame) */
+    int32_t frame_rows, row0;   /* rows of the whole frame, and the strip's first row in it */
+    const orc_scene_info *scene;
+    const orc_light_info *lights; int32_t n_lights;
+    const float *verts; int32_t n_verts;       /* light-volume mesh, 3 floats per vertex */
+    const uint32_t *indices; int32_t n_tris;   /* 3 indices per triangle */
+    uint64_t *masks;            /* n_lights * ceil(rows/8) * ceil(width/8) */
+} orc_coverage_args;
+
+/* row-major 4x4 product in the row-vector convention: c = a * b, each element one fma chain */
+static void mat4_mul(const float *a, const float *b, float *c)
+{
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++)
+            c[4 * i + j] = fmaf(a[4 * i + 3], b[12 + j], fmaf(a[4 * i + 2], b[8 + j], fmaf(a[4 * i + 1], b[4 + j], a[4 * i] * b[j])));
+}
+
+/* light.vert:26 evaluated left to right: (proj * view) * model, then times the vertex */
+static void light_mvp(const orc_scene_info *scene, const orc_light_info *lt, float *mvp)
+{
+    float vp[16];
+    mat4_mul(scene->camera_view, scene->camera_proj, vp);
+    mat4_mul(lt->model, vp, mvp);
+}
+
+static void clip_vertex(const float *mvp, const float *v, float *out4)
+{
+    for (int j = 0; j < 4; j++)
+        out4[j] = fmaf(v[2], mvp[8 + j], fmaf(v[1], mvp[4 + j], v[0] * mvp[j])) + mvp[12 + j];
+}
+
+typedef struct { double a[3], b[3], c[3], z[3], D; } cov_tri;
+
+static int cov_setup(const float *c0, const float *c1, const float *c2, cov_tri *t)
+{
+    const double x0 = c0[0], y0 = c0[1], z0 = c0[2], w0 = c0[3];
+    const double x1 = c1[0], y1 = c1[1], z1 = c1[2], w1 = c1[3];
+    const double x2 = c2[0], y2 = c2[1], z2 = c2[2], w2 = c2[3];
+    t->a[0] = y1 * w2 - w1 * y2; t->b[0] = w1 * x2 - x1 * w2; t->c[0] = x1 * y2 - y1 * x2;
+    t->a[1] = y2 * w0 - w2 * y0; t->b[1] = w2 * x0 - x2 * w0; t->c[1] = x2 * y0 - y2 * x0;
+    t->a[2] = y0 * w1 - w0 * y1; t->b[2] = w0 * x1 - x0 * w1; t->c[2] = x0 * y1 - y0 * x1;
+    t->z[0] = z0; t->z[1] = z1; t->z[2] = z2;
+    t->D = fma(w0, t->c[0], fma(y0, t->b[0], x0 * t->a[0]));
+    return t->D > 0.0; /* back face; front faces and degenerate triangles are culled */
+}
+
+static inline double cov_edge(const cov_tri *t, int i, double xn, double yn) { return fma(t->a[i], xn, fma(t->b[i], yn, t->c[i])); }
+
+static inline int cov_inside(const cov_tri *t, double xn, double yn)
+{
+    const double e0 = cov_edge(t, 0, xn, yn), e1 = cov_edge(t, 1, xn, yn), e2 = cov_edge(t, 2, xn, yn);
+    if (!(e0 >= 0.0 && e1 >= 0.0 && e2 >= 0.0 && (e0 + e1) + e2 > 0.0)) return 0;
+    const double zs = fma(e2, t->z[2], fma(e1, t->z[1], e0 * t->z[0]));
+    return zs >= 0.0 && zs <= t->D;
+}
+
+#define COV_MACRO 128 /* triangles are first tested against 128x128-pixel blocks */
+
+ORC_API void orc_light_coverage(const orc_coverage_args *a)
+{
+    const int tiles_x = (a->width + 7) / 8, tiles_y = (a->rows + 7) / 8;
+    const int mx = (a->width + COV_MACRO - 1) / COV_MACRO, my = (a->rows + COV_MACRO - 1) / COV_MACRO;
+    const double sx = 2.0 / (double)a->width, sy = 2.0 / (double)a->frame_rows;
+    memset(a->masks, 0, (size_t)a->n_lights * tiles_x * tiles_y * sizeof(uint64_t));
+    float *clip = (float *)malloc((size_t)a->n_verts * 4 * sizeof(float));
+    cov_tri *tris = (cov_tri *)malloc((size_t)a->n_tris * sizeof(cov_tri));
+    for (int li = 0; li < a->n_lights; li++) {
+        float mvp[16];
+        light_mvp(a->scene, a->lights + li, mvp);
+        for (int v = 0; v < a->n_verts; v++) clip_vertex(mvp, a->verts + 3 * v, clip + 4 * v);
+        int nback = 0;
+        for (int t = 0; t < a->n_tris; t++) {
+            cov_tri tri;
+            if (cov_setup(clip + 4 * a->indices[3 * t], clip + 4 * a->indices[3 * t + 1], clip + 4 * a->indices[3 * t + 2], &tri)) tris[nback++] = tri;
+        }
+        uint64_t *masks = a->masks + (size_t)li * tiles_x * tiles_y;
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int mb = 0; mb < mx * my; mb++) {
+            const int bx0 = (mb % mx) * COV_MACRO, by0 = (mb / mx) * COV_MACRO;
+            const int bx1 = bx0 + COV_MACRO < a->width ? bx0 + COV_MACRO : a->width, by1 = by0 + COV_MACRO < a->rows ? by0 + COV_MACRO : a->rows;
+            /* centres of the block's corner pixels */
+            const double xa = fma((double)bx0 + 0.5, sx, -1.0), xb = fma((double)(bx1 - 1) + 0.5, sx, -1.0);
+            const double ya = fma((double)(a->row0 + by0) + 0.5, sy, -1.0), yb = fma((double)(a->row0 + by1 - 1) + 0.5, sy, -1.0);
+            for (int t = 0; t < nback; t++) {
+                const cov_tri *tri = tris + t;
+                int reject = 0;
+                for (int i = 0; i < 3 && !reject; i++) /* an edge with all four corners outside rules the block out */
+                    reject = cov_edge(tri, i, xa, ya) < 0.0 && cov_edge(tri, i, xb, ya) < 0.0 && cov_edge(tri, i, xa, yb) < 0.0 && cov_edge(tri, i, xb, yb) < 0.0;
+                if (reject) continue;
+                for (int y = by0; y < by1; y++) {
+                    const double yn = fma((double)(a->row0 + y) + 0.5, sy, -1.0);
+                    for (int x = bx0; x < bx1; x++) {
+                        uint64_t *m = masks + (size_t)(y / 8) * tiles_x + x / 8;
+                        const uint64_t bit = 1ull << ((y & 7) * 8 + (x & 7));
+                        if (*m & bit) continue;
+                        if (cov_inside(tri, fma((double)x + 0.5, sx, -1.0), yn)) *m |= bit;
+                    }
+                }
+            }
+        }
+    }
+    free(tris);
+    free(clip);
+}
+
+/* probes for the known-answer tests */
+ORC_API void orc_light_clip_vertex(const orc_scene_info *scene, const orc_light_info *lt, const float *v3in, float *out4)
+{
+    float mvp[16];
+    light_mvp(scene, lt, mvp);
+    clip_vertex(mvp, v3in, out4);
 }
 
 /* ------------------------------------------------------------------------------------------ */

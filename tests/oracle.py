@@ -28,7 +28,15 @@ class ShadeArgs(C.Structure):
                 ("irradiance", C.c_void_p), ("irr_res", C.c_int32),
                 ("prefilter", C.c_void_p), ("pref_res", C.c_int32),
                 ("brdf_lut", C.c_void_p), ("lut_res", C.c_int32),
-                ("out_color", C.c_void_p), ("out_threshold", C.c_void_p)]
+                ("out_color", C.c_void_p), ("out_threshold", C.c_void_p), ("coverage", C.c_void_p)]
+
+
+class CoverageArgs(C.Structure):
+    _fields_ = [("width", C.c_int32), ("rows", C.c_int32), ("frame_rows", C.c_int32), ("row0", C.c_int32),
+                ("scene", C.c_void_p), ("lights", C.c_void_p), ("n_lights", C.c_int32),
+                ("verts", C.c_void_p), ("n_verts", C.c_int32),
+                ("indices", C.c_void_p), ("n_tris", C.c_int32),
+                ("masks", C.c_void_p)]
 
 
 def build() -> None:
@@ -79,8 +87,44 @@ def f16_to_f32(a: np.ndarray) -> np.ndarray:
     return out
 
 
-def shade(f, background: np.ndarray | None = None, rows: tuple[int, int] | None = None):
-    """Composition pass on a synth.FrameInputs; returns (color, threshold) uint16 [H, W, 4]."""
+def light_coverage(scene: np.ndarray, lights: np.ndarray, verts: np.ndarray, indices: np.ndarray,
+                   width: int, rows: int, frame_rows: int | None = None, row0: int = 0) -> np.ndarray:
+    """Light-volume coverage masks uint64 [n_lights, ceil(rows/8), ceil(width/8)]: bit (y&7)*8 + (x&7)."""
+    scene = np.ascontiguousarray(scene).reshape(1)
+    lights = np.ascontiguousarray(lights)
+    verts = np.ascontiguousarray(verts, dtype=np.float32)
+    indices = np.ascontiguousarray(indices, dtype=np.uint32)
+    masks = np.zeros((len(lights), (rows + 7) // 8, (width + 7) // 8), dtype=np.uint64)
+    a = CoverageArgs()
+    a.width, a.rows, a.frame_rows, a.row0 = width, rows, rows if frame_rows is None else frame_rows, row0
+    a.scene, a.lights, a.n_lights = _p(scene), (_p(lights) if len(lights) else C.c_void_p(0)), len(lights)
+    a.verts, a.n_verts = _p(verts), len(verts)
+    a.indices, a.n_tris = _p(indices), len(indices) // 3 if indices.ndim == 1 else len(indices)
+    a.masks = _p(masks)
+    load().orc_light_coverage(C.byref(a))
+    return masks
+
+
+def coverage_to_image(masks: np.ndarray, width: int, rows: int) -> np.ndarray:
+    """bool [n_lights, rows, width] from the tile masks."""
+    n, ty, tx = masks.shape
+    bits = (masks[..., None] >> np.arange(64, dtype=np.uint64)) & np.uint64(1)
+    img = bits.reshape(n, ty, tx, 8, 8).transpose(0, 1, 3, 2, 4).reshape(n, ty * 8, tx * 8)
+    return img[:, :rows, :width].astype(bool)
+
+
+def light_clip_vertex(scene: np.ndarray, light: np.ndarray, v) -> np.ndarray:
+    scene = np.ascontiguousarray(scene).reshape(1)
+    light = np.ascontiguousarray(light).reshape(1)
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    out = np.empty(4, dtype=np.float32)
+    load().orc_light_clip_vertex(_p(scene), _p(light), _p(v), _p(out))
+    return out
+
+
+def shade(f, background: np.ndarray | None = None, rows: tuple[int, int] | None = None, coverage: np.ndarray | None = None):
+    """Composition pass on a synth.FrameInputs; returns (color, threshold) uint16 [H, W, 4].
+    `coverage`: masks from light_coverage (None: every light covers every pixel)."""
     lib = load()
     color = np.zeros((f.height, f.width, 4), dtype=np.uint16)
     thr = np.zeros((f.height, f.width, 4), dtype=np.uint16)
@@ -98,6 +142,7 @@ def shade(f, background: np.ndarray | None = None, rows: tuple[int, int] | None 
     a.prefilter, a.pref_res = _p(f.prefilter), f.prefilter.shape[1]
     a.brdf_lut, a.lut_res = _p(f.brdf_lut), f.brdf_lut.shape[0]
     a.out_color, a.out_threshold = _p(color), _p(thr)
+    a.coverage = _p(None if coverage is None else np.ascontiguousarray(coverage, dtype=np.uint64))
     r0, r1 = (0, f.height) if rows is None else rows
     lib.orc_shade(C.byref(a), r0, r1)
     return color, thr

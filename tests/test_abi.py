@@ -96,3 +96,28 @@ def test_cpp_host_wrapper_compiles_against_the_header(tmp_path):
     csrc.write_text('#include "vkr_hip.h"\nint size(void) { return (int)sizeof(VkrSceneInfo) + (int)sizeof(VkrLightInfo); }\n'
                     '_Static_assert(sizeof(VkrSceneInfo) == 240, "SceneInfo"); _Static_assert(sizeof(VkrLightInfo) == 92, "LightInfo");\n')
     subprocess.run(["gcc", "-std=c11", "-fsyntax-only", "-Wall", "-I", os.path.join(ROOT, "include"), str(csrc)], check=True)
+
+
+def test_ctypes_structs_have_the_headers_layout(tmp_path):
+    """Every argument struct of the binding has the size and field offsets the C compiler gives the
+    header's struct (a field added on one side only would shift everything behind it)."""
+    import ctypes as C
+    import subprocess
+    from vulkanrenderer_amd import _lib
+    pairs = {"VkrShadeArgs": _lib.ShadeArgs, "VkrCoverageArgs": _lib.CoverageArgs, "VkrBloomArgs": _lib.BloomArgs,
+             "VkrBloomPostArgs": _lib.BloomPostArgs, "VkrSceneInfo": _lib.SceneInfo, "VkrLightInfo": _lib.LightInfo}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "vkr_hip.h"', 'int main(void) {']
+    for cname, ct in pairs.items():
+        lines.append(f'  printf("{cname} %zu", sizeof({cname}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'  printf(" %zu", offsetof({cname}, {fname}));')
+        lines.append('  printf("\\n");')
+    lines += ['  return 0;', '}']
+    src, exe = tmp_path / "layout.c", tmp_path / "layout"
+    src.write_text("\n".join(lines))
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines()
+    for line, (cname, ct) in zip(out, pairs.items()):
+        name, size, *offsets = line.split()
+        assert name == cname and int(size) == C.sizeof(ct), f"{cname}: C {size} bytes, ctypes {C.sizeof(ct)}"
+        assert [int(o) for o in offsets] == [getattr(ct, f).offset for f, _ in ct._fields_], cname

@@ -404,3 +404,83 @@ def test_tiled_environment_cube(gpu, oracle):
         P.tile_env_cube(odd)
     with pytest.raises(_lib.VkrError):
         P.irradiance(odd, irr, 0, env_layout=T)
+
+
+def _camera_scene(cam, target=(0.0, 0.0, 0.0), aspect=16.0 / 9.0):
+    s = synth.default_scene_info().copy()
+    s["camera_view"] = synth.look_at(cam, target, (0, 1, 0)).astype(np.float32).ravel()
+    s["camera_projection"] = synth.perspective(60.0, aspect, 0.1, 100.0).astype(np.float32).ravel()
+    s["camera_position"] = cam
+    return s
+
+
+def _small_lights(rng, n, scale):
+    """Lights whose volumes are much smaller than the reference's (colour maximum `scale` * U[0.2,1])."""
+    lights = synth.make_lights(rng, n)
+    for i in range(n):
+        lights["color"][i] *= scale
+        r = synth.light_volume_radius(lights["color"][i])
+        m = np.diag([r, r, r, 1.0])
+        m[3, :3] = lights["position"][i]
+        lights["model"][i] = m.astype(np.float32).ravel()
+    return lights
+
+
+@pytest.mark.parametrize("w,h,row0,frame_rows", [(200, 120, 0, 120), (131, 77, 0, 77), (160, 45, 37, 120)])
+def test_light_coverage_masks_bit_exact(gpu, oracle, w, h, row0, frame_rows):
+    """vkr_light_coverage against the oracle's rasterisation: volumes in front of, around and behind
+    the camera, partly off screen, one beyond the far plane; whole frames and a strip of a frame."""
+    torch, P = _torch(), _passes()
+    verts, tris = synth.make_sphere_mesh()
+    f = synth.make_frame(61, w, h, 9, 16, 64, irr_res=8, pref_res=16, lut_res=32)
+    f.scene = _camera_scene((2.0, 1.0, -4.0), aspect=w / frame_rows)
+    f.lights = _small_lights(np.random.default_rng(5), 9, 0.01)
+    # hand-placed cases: around the camera, behind it, far away, beyond the far plane
+    for i, (pos, r) in enumerate([((2.0, 1.0, -4.0), 1.0), ((4.0, 2.0, -8.0), 1.5), ((-30.0, -10.0, 60.0), 6.0), ((-60.0, -25.0, 118.0), 5.0)]):
+        m = np.diag([r, r, r, 1.0]); m[3, :3] = pos
+        f.lights["model"][i] = m.astype(np.float32).ravel()
+        f.lights["position"][i] = pos
+    want = oracle.light_coverage(f.scene, f.lights, verts, tris, w, h, frame_rows, row0)
+    img = oracle.coverage_to_image(want, w, h)
+    assert img[0].all() and not img[1].any() and img[2].any() and not img[3].any()
+    assert 0 < img[4:].sum() < img[4:].size
+    d = P.DeviceFrame.upload(f, gpu)
+    got = P.light_coverage(d, torch.from_numpy(verts).to(gpu), torch.from_numpy(tris.astype(np.int32)).to(gpu), frame_rows, row0)
+    got = got.cpu().numpy().view(np.uint64)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), f"{(got != want).sum()} of {got.size} tile masks differ"
+
+
+def test_shade_with_light_volume_coverage(gpu, oracle):
+    """Composition with VKR_COVERAGE_MESH: small light volumes, so most draws touch part of the frame
+    only; bit-exact against the oracle using the same masks, and equal to full coverage when every
+    volume contains the camera."""
+    torch, P = _torch(), _passes()
+    w, h, nl = 176, 104, 7
+    verts, tris = synth.make_sphere_mesh()
+    dverts, dtris = torch.from_numpy(verts).to(gpu), torch.from_numpy(tris.astype(np.int32)).to(gpu)
+    f = synth.make_frame(62, w, h, nl, 32, 128, irr_res=8, pref_res=16, lut_res=32)
+    f.scene = _camera_scene((2.0, 1.0, -4.0), aspect=w / h)
+    color = torch.empty((h, w, 4), dtype=torch.float16, device=gpu)
+    thr = torch.empty_like(color)
+
+    d = P.DeviceFrame.upload(f, gpu)          # the reference's radii: every volume contains the camera
+    P.shade(d, color, thr)
+    full_c, full_t = P.f16_bits(color).copy(), P.f16_bits(thr).copy()
+    d.coverage = P.light_coverage(d, dverts, dtris)
+    assert bool((d.coverage == -1).all())     # every bit set
+    P.shade(d, color, thr)
+    assert np.array_equal(P.f16_bits(color), full_c) and np.array_equal(P.f16_bits(thr), full_t)
+
+    f.lights = _small_lights(np.random.default_rng(8), nl, 0.02)
+    d = P.DeviceFrame.upload(f, gpu)
+    d.coverage = P.light_coverage(d, dverts, dtris)
+    masks = oracle.light_coverage(f.scene, f.lights, verts, tris, w, h)
+    assert np.array_equal(d.coverage.cpu().numpy().view(np.uint64), masks)
+    frac = oracle.coverage_to_image(masks, w, h).mean()
+    assert 0.02 < frac < 0.9, frac
+    P.shade(d, color, thr)
+    want_c, want_t = oracle.shade(f, coverage=masks)
+    assert_bits_equal(P.f16_bits(color), want_c, "composition colour with light-volume coverage")
+    assert_bits_equal(P.f16_bits(thr), want_t, "thresholded colour with light-volume coverage")
+    assert not np.array_equal(want_c, oracle.shade(f)[0])  # the masks do change the image

@@ -325,3 +325,83 @@ def test_ambient_uses_f_times_brdf_x_times_brdf_y(oracle):
     f.brdf_lut = f16(lut)
     c = oracle.f16_to_f32(oracle.shade(f)[0])[0, 0, 0]
     assert c == pytest.approx(2.0 * (0.04 * 0.5 * 0.25), rel=2e-3)  # N.V = 1 -> F = F0 = 0.04
+
+
+# ---- light-volume coverage (light.vert + the rasteriser's rules; no reference file pins these) ----
+
+def _coverage_scene(cam, target=(0.0, 0.0, 0.0), aspect=16.0 / 9.0):
+    from vulkanrenderer_amd import synth
+    s = synth.default_scene_info().copy()
+    s["camera_view"] = synth.look_at(cam, target, (0, 1, 0)).astype(np.float32).ravel()
+    s["camera_projection"] = synth.perspective(60.0, aspect, 0.1, 100.0).astype(np.float32).ravel()
+    s["camera_position"] = cam
+    return s
+
+
+def _volume(pos, radius):
+    from vulkanrenderer_amd import synth
+    l = np.zeros(1, dtype=synth.LIGHT_DTYPE)
+    m = np.diag([radius, radius, radius, 1.0])
+    m[3, :3] = pos
+    l["model"][0] = m.astype(np.float32).ravel()  # Light.ToInfo: Scale(radius) * Translate(position), Light.cs:10-18
+    l["position"][0] = pos
+    return l
+
+
+def test_coverage_of_a_sphere_on_the_view_axis_is_its_silhouette_disc(oracle):
+    from vulkanrenderer_amd import synth
+    w, h = 320, 180
+    verts, tris = synth.make_sphere_mesh()
+    scene = _coverage_scene((0.0, 0.0, 5.0))
+    img = oracle.coverage_to_image(oracle.light_coverage(scene, _volume((0, 0, 0), 1.0), verts, tris, w, h), w, h)[0]
+    # a unit sphere 5 away: silhouette cone of half-angle asin(1/5); the 32x16 mesh is inscribed, so it
+    # covers slightly less than the disc and never more
+    f = 1.0 / np.tan(np.radians(30.0))
+    ys, xs = np.mgrid[0:h, 0:w]
+    xn, yn = (xs + 0.5) / w * 2 - 1, (ys + 0.5) / h * 2 - 1
+    r2 = (xn * 16 / 9) ** 2 + yn ** 2
+    rad = np.tan(np.arcsin(0.2)) * f
+    assert not (img & (r2 > rad ** 2)).any()
+    assert (img | (r2 > (0.985 * rad) ** 2)).all()
+    assert img.sum() > 0.97 * (r2 <= rad ** 2).sum()
+
+
+def test_coverage_inside_behind_and_beyond_the_far_plane(oracle):
+    from vulkanrenderer_amd import synth
+    w, h = 96, 54
+    verts, tris = synth.make_sphere_mesh()
+    scene = _coverage_scene((0.0, 0.0, 5.0))
+    cover = lambda pos, r: oracle.coverage_to_image(oracle.light_coverage(scene, _volume(pos, r), verts, tris, w, h), w, h)[0]
+    assert cover((0, 0, 4), 3.0).all()          # camera inside the volume: its back faces surround the view
+    assert not cover((0, 0, 12), 1.0).any()     # behind the camera
+    assert not cover((0, 0, -97), 5.0).any()    # back faces beyond the far plane (100) are clipped, front faces culled
+    assert cover((0, 0, -90), 5.0).any()        # same sphere a little nearer: back faces at 95..100 survive
+    half = cover((0, 0, 3.0), 1.95)             # volume cut by the near plane region in front of the camera
+    assert half.any()
+
+
+def test_coverage_of_a_strip_is_the_strip_of_the_frame_coverage(oracle):
+    from vulkanrenderer_amd import synth
+    w, h = 120, 96
+    verts, tris = synth.make_sphere_mesh()
+    scene = _coverage_scene((2.0, 1.0, -4.0), aspect=w / h)
+    lights = np.concatenate([_volume((0.5, 0.2, 0.0), 1.2), _volume((3.0, 1.5, -6.0), 1.0), _volume((-1.0, 0.0, 2.0), 2.5)])
+    whole = oracle.coverage_to_image(oracle.light_coverage(scene, lights, verts, tris, w, h), w, h)
+    assert 0 < whole.sum() < whole.size
+    for row0, rows in [(0, 40), (40, 37), (77, 19)]:   # strips need not start on a tile boundary
+        part = oracle.coverage_to_image(oracle.light_coverage(scene, lights, verts, tris, w, rows, h, row0), w, rows)
+        assert np.array_equal(part, whole[:, row0:row0 + rows])
+
+
+def test_light_vertex_transform_is_proj_view_model(oracle):
+    from vulkanrenderer_amd import synth
+    scene = _coverage_scene((2.0, 1.0, -4.0))
+    light = _volume((1.0, 2.0, 3.0), 7.5)
+    v = np.array([0.3, -0.4, 0.5], dtype=np.float32)
+    got = oracle.light_clip_vertex(scene, light, v)
+    M = light["model"][0].reshape(4, 4).astype(np.float64)
+    V = scene["camera_view"].reshape(4, 4).astype(np.float64)
+    P = scene["camera_projection"].reshape(4, 4).astype(np.float64)
+    want = np.append(v.astype(np.float64), 1.0) @ M @ V @ P
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-5)
+    assert want[3] > 0  # in front of the camera

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("VKR_HIP_LIB") or os.path.join(_HERE, "libvkr_hip.so")
 
 VKR_OK = 0
 VKR_ERR_INVALID, VKR_ERR_HIP, VKR_ERR_UNSUPPORTED, VKR_ERR_ORDER, VKR_ERR_NO_DEVICE = -1, -2, -3, -4, -5
-COVERAGE_FULLSCREEN = 0
+COVERAGE_FULLSCREEN, COVERAGE_MESH = 0, 1
 CUBE_LAYOUT_LINEAR, CUBE_LAYOUT_TILED_8X4 = 0, 1
 ENV_LAYOUT_LINEAR, ENV_LAYOUT_TILED_4X4 = 0, 1
 WRAP_REPEAT, WRAP_CLAMP = 0, 1
@@ -53,12 +53,22 @@ class ShadeArgs(C.Structure):
                 ("background", C.c_void_p),
                 ("scene", SceneInfo),
                 ("lights", C.c_void_p), ("n_lights", C.c_int32), ("coverage_mode", C.c_int32),
+                ("coverage_masks", C.c_void_p),
                 ("dir_shadow", C.c_void_p), ("dir_res", C.c_int32),
                 ("cube_shadow", C.c_void_p), ("cube_res", C.c_int32), ("cube_layout", C.c_int32),
                 ("irradiance", C.c_void_p), ("irr_res", C.c_int32),
                 ("prefilter", C.c_void_p), ("pref_res", C.c_int32),
                 ("brdf_lut", C.c_void_p), ("lut_res", C.c_int32),
                 ("out_color", C.c_void_p), ("out_threshold", C.c_void_p)]
+
+
+class CoverageArgs(C.Structure):
+    _fields_ = [("width", C.c_int32), ("rows", C.c_int32), ("frame_rows", C.c_int32), ("row0", C.c_int32),
+                ("scene", SceneInfo),
+                ("lights", C.c_void_p), ("n_lights", C.c_int32),
+                ("verts", C.c_void_p), ("n_verts", C.c_int32),
+                ("indices", C.c_void_p), ("n_tris", C.c_int32),
+                ("masks", C.c_void_p)]
 
 
 class BloomArgs(C.Structure):
@@ -92,6 +102,7 @@ PROTOTYPES = {
     "vkr_device_count": [],
     "vkr_shade": [C.POINTER(ShadeArgs), _vp],
     "vkr_tile_depth_cubes": [_vp, _vp, C.c_int32, C.c_int32, _vp],
+    "vkr_light_coverage": [C.POINTER(CoverageArgs), _vp],
     "vkr_bloom_blur": [C.POINTER(BloomArgs), _vp],
     "vkr_postprocess": [_vp, _vp, _vp, _i32, _i32, _i32, _vp],
     "vkr_bloomv_postprocess": [C.POINTER(BloomPostArgs), _vp],

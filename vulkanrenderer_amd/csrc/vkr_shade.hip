@@ -32,6 +32,7 @@ struct ShadeParams {
     const void *prefilter; int pref_res;
     const uint32_t *brdf_lut; int lut_res;
     uint2 *out_color, *out_threshold;
+    const unsigned long long *coverage;  // per (light, 8x8 tile) masks, or null
     float cam[3];
     float dir_dir[3];
     float dir_color[3];
@@ -280,7 +281,9 @@ VKR_DEV void tile_of_block(unsigned b, int tiles_x, int tiles_y, int &tx, int &t
 // Six waves per SIMD (80 VGPRs): the ten values the register allocator spills for that are used
 // only before and after the light loop, which itself touches no scratch memory.  Measured at
 // 4K / 64 lights: 4 waves 5.5 ms, 5 waves 4.6, 6 waves 4.5, 7 waves (spills inside the loop) 4.6.
-template <bool TILED, bool POW2>
+// MASKED: each light's draw touches only the pixels its light volume covers (one 64-bit mask per
+// light and tile, bit = lane); a light that covers none of the wave's pixels is skipped whole.
+template <bool TILED, bool POW2, bool MASKED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void shade_kernel(const ShadeParams p)
 {
     // one wave per workgroup, one 8x8-pixel tile per wave
@@ -376,12 +379,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             lp_next = mk3(lights_c[16], lights_c[17], lights_c[18]);
             lc_next = mk3(lights_c[20], lights_c[21], lights_c[22]);
         }
+        typedef const __attribute__((address_space(4))) unsigned long long cmask;
+        cmask *cover_c = (cmask *)p.coverage;
+        const size_t tiles = (size_t)p.tiles_x * p.tiles_y, tile = (size_t)tile_y * p.tiles_x + tile_x;
         for (int li = 0; li < p.n_lights; li++) {
             const f3 lp = lp_next, lc = lc_next;
             {
                 cfloat *lf = lights_c + min(li + 1, p.n_lights - 1) * 23;
                 lp_next = mk3(lf[16], lf[17], lf[18]);
                 lc_next = mk3(lf[20], lf[21], lf[22]);
+            }
+            bool covered = true;
+            if (MASKED) {
+                const unsigned long long m = cover_c[(size_t)li * tiles + tile];  // wave-uniform: a scalar load
+                if (m == 0) continue;
+                covered = (m >> lane) & 1ull;
             }
             const f3 Lv = sub3(lp, pos);
             float dist, inv_dist;
@@ -400,7 +412,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             // every lane the result is the same zero (or NaN) whatever the taps say, so a wave that
             // faces away from the light skips them.
             int count = 0;
-            if (!__any(NdotL > 0.0f)) {
+            if (!__any(covered && NdotL > 0.0f)) {
             } else if (face0 >= 0 && __all(face == face0)) {
                 const float *fb = cube + (size_t)face0 * face_stride;
                 const bool neg = face0 & 1;
@@ -427,8 +439,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             const float o0 = ((fma_((1.0f - F.x) * albedo.x, INV_PI, (DG * F.x) * isd) * (lc.x * att)) * lit) * NdotL;
             const float o1 = ((fma_((1.0f - F.y) * albedo.y, INV_PI, (DG * F.y) * isd) * (lc.y * att)) * lit) * NdotL;
             const float o2 = ((fma_((1.0f - F.z) * albedo.z, INV_PI, (DG * F.z) * isd) * (lc.z * att)) * lit) * NdotL;
-            const bool bright = luminance(o0, o1, o2) > 1.0f;  // light.frag:78-82
-            c0 = round_f16(c0 + o0); c1 = round_f16(c1 + o1); c2 = round_f16(c2 + o2);
+            const bool bright = covered && luminance(o0, o1, o2) > 1.0f;  // light.frag:78-82
+            if (MASKED) {  // an uncovered pixel is not part of this draw: its targets keep their bits
+                c0 = covered ? round_f16(c0 + o0) : c0; c1 = covered ? round_f16(c1 + o1) : c1; c2 = covered ? round_f16(c2 + o2) : c2;
+            } else {
+                c0 = round_f16(c0 + o0); c1 = round_f16(c1 + o1); c2 = round_f16(c2 + o2);
+            }
             if (__any(bright)) {  // adding 0 to the thresholded target changes nothing
                 t0 = round_f16(t0 + (bright ? o0 : 0.0f));
                 t1 = round_f16(t1 + (bright ? o1 : 0.0f));
@@ -484,8 +500,8 @@ extern "C" int32_t vkr_shade(const VkrShadeArgs *a, void *stream)
     VKR_REQUIRE(a->dir_shadow && a->dir_res > 0, "vkr_shade: directional shadow map missing");
     VKR_REQUIRE(a->irradiance && a->irr_res > 0 && a->prefilter && a->pref_res > 0 && a->brdf_lut && a->lut_res > 0, "vkr_shade: an IBL image is missing");
     VKR_REQUIRE((int64_t)a->dir_res * a->dir_res < (1ll << 31), "vkr_shade: directional shadow map too large");
-    if (a->coverage_mode != VKR_COVERAGE_FULLSCREEN)
-        return fail(VKR_ERR_UNSUPPORTED, "vkr_shade: coverage mode %d is not implemented", a->coverage_mode);
+    VKR_REQUIRE(a->coverage_mode == VKR_COVERAGE_FULLSCREEN || a->coverage_mode == VKR_COVERAGE_MESH, "vkr_shade: unknown coverage mode %d", a->coverage_mode);
+    VKR_REQUIRE(a->coverage_mode != VKR_COVERAGE_MESH || a->n_lights == 0 || a->coverage_masks, "vkr_shade: VKR_COVERAGE_MESH needs coverage_masks (see vkr_light_coverage)");
     VKR_REQUIRE(a->cube_layout == VKR_CUBE_LAYOUT_LINEAR || a->cube_layout == VKR_CUBE_LAYOUT_TILED_8X4, "vkr_shade: unknown cube shadow layout %d", a->cube_layout);
     VKR_REQUIRE(a->cube_layout == VKR_CUBE_LAYOUT_LINEAR || a->n_lights == 0 || a->cube_res % 8 == 0, "vkr_shade: the tiled cube shadow layout needs a face size that is a multiple of 8 (got %d)", a->cube_res);
 
@@ -500,6 +516,7 @@ extern "C" int32_t vkr_shade(const VkrShadeArgs *a, void *stream)
     p.prefilter = a->prefilter; p.pref_res = a->pref_res;
     p.brdf_lut = (const uint32_t *)a->brdf_lut; p.lut_res = a->lut_res;
     p.out_color = (uint2 *)a->out_color; p.out_threshold = (uint2 *)a->out_threshold;
+    p.coverage = a->coverage_mode == VKR_COVERAGE_MESH ? (const unsigned long long *)a->coverage_masks : nullptr;
     for (int i = 0; i < 3; i++) {
         p.cam[i] = a->scene.camera_position[i];
         p.dir_dir[i] = a->scene.dir_light_direction[i];
@@ -512,8 +529,11 @@ extern "C" int32_t vkr_shade(const VkrShadeArgs *a, void *stream)
     const dim3 grid((unsigned)(p.tiles_x * p.tiles_y));
     const bool tiled = a->cube_layout == VKR_CUBE_LAYOUT_TILED_8X4;
     const bool pow2 = a->n_lights > 0 && (a->cube_res & (a->cube_res - 1)) == 0;
-    auto kernel = tiled ? (pow2 ? shade_kernel<true, true> : shade_kernel<true, false>)
-                        : (pow2 ? shade_kernel<false, true> : shade_kernel<false, false>);
+    const bool masked = p.coverage != nullptr;
+    typedef void (*kernel_t)(const ShadeParams);
+    static const kernel_t kernels[8] = {shade_kernel<false, false, false>, shade_kernel<false, false, true>, shade_kernel<false, true, false>, shade_kernel<false, true, true>,
+                                        shade_kernel<true, false, false>,  shade_kernel<true, false, true>,  shade_kernel<true, true, false>,  shade_kernel<true, true, true>};
+    const kernel_t kernel = kernels[(tiled ? 4 : 0) + (pow2 ? 2 : 0) + (masked ? 1 : 0)];
     hipLaunchKernelGGL(kernel, grid, dim3(64), 0, as_stream(stream), p);
     return launch_status("vkr_shade");
 }

@@ -57,6 +57,7 @@ class DeviceFrame:
     brdf_lut: torch.Tensor
     background: torch.Tensor | None = None
     cube_layout: int = _lib.CUBE_LAYOUT_LINEAR
+    coverage: torch.Tensor | None = None  # masks from light_coverage(); None: every light covers every pixel
 
     @staticmethod
     def upload(f: FrameInputs, device, tiled: bool | None = None) -> "DeviceFrame":
@@ -81,6 +82,24 @@ class DeviceFrame:
             to_device_f16(f.irradiance, device), to_device_f16(f.prefilter, device), to_device_f16(f.brdf_lut, device))
 
 
+def light_coverage(f: DeviceFrame, verts: torch.Tensor, indices: torch.Tensor,
+                   frame_rows: int | None = None, row0: int = 0) -> torch.Tensor:
+    """Light-volume coverage of the frame's lights: int64 tensor [n_lights, ceil(rows/8), ceil(width/8)] of
+    64-bit tile masks (bit (y&7)*8 + (x&7)).  `verts` [n,3] float32, `indices` [m,3] int32 on the device;
+    `frame_rows` / `row0` place a strip inside the whole frame."""
+    lib = _lib.load()
+    masks = torch.empty((f.n_lights, (f.rows + 7) // 8, (f.width + 7) // 8), dtype=torch.int64, device=f.albedo.device)
+    a = _lib.CoverageArgs()
+    a.width, a.rows, a.frame_rows, a.row0 = f.width, f.rows, f.rows if frame_rows is None else frame_rows, row0
+    a.scene = _scene_struct(f.scene)
+    a.lights, a.n_lights = _ptr(f.lights), f.n_lights
+    a.verts, a.n_verts = _ptr(verts), verts.shape[0]
+    a.indices, a.n_tris = _ptr(indices), indices.shape[0]
+    a.masks = _ptr(masks)
+    _lib.check(lib.vkr_light_coverage(C.byref(a), _stream()))
+    return masks
+
+
 def tile_depth_cubes(linear: torch.Tensor) -> torch.Tensor:
     """[..., res, res] float32 depth faces, row-major -> the same faces as 8x4-texel tiles (new tensor)."""
     lib = _lib.load()
@@ -103,7 +122,9 @@ def shade(f: DeviceFrame, out_color: torch.Tensor, out_threshold: torch.Tensor) 
     a.albedo, a.normal, a.arm, a.position = _ptr(f.albedo), _ptr(f.normal), _ptr(f.arm), _ptr(f.position)
     a.background = _ptr(f.background)
     a.scene = _scene_struct(f.scene)
-    a.lights, a.n_lights, a.coverage_mode = _ptr(f.lights), f.n_lights, _lib.COVERAGE_FULLSCREEN
+    a.lights, a.n_lights = _ptr(f.lights), f.n_lights
+    a.coverage_mode = _lib.COVERAGE_FULLSCREEN if f.coverage is None else _lib.COVERAGE_MESH
+    a.coverage_masks = _ptr(f.coverage)
     a.dir_shadow, a.dir_res = _ptr(f.dir_shadow), f.dir_shadow.shape[-1]
     a.cube_shadow, a.cube_res, a.cube_layout = _ptr(f.cube_shadow), f.cube_shadow.shape[-1], f.cube_layout
     a.irradiance, a.irr_res = _ptr(f.irradiance), f.irradiance.shape[1]

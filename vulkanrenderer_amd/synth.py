@@ -73,12 +73,55 @@ LIGHT_DTYPE = np.dtype([
 assert SCENE_DTYPE.itemsize == 240 and LIGHT_DTYPE.itemsize == 92  # VulkanRenderer.cs:11-28
 
 
+def perspective(fov_degrees: float, aspect: float, near: float, far: float) -> np.ndarray:
+    """Camera.GetProjectionMatrix (Camera.cs:30-35): right-handed CreatePerspectiveFieldOfView, depth 0..1,
+    row-vector convention, with M22 negated because Vulkan's y points down."""
+    f = 1.0 / np.tan(np.radians(fov_degrees) * 0.5)
+    m = np.zeros((4, 4), dtype=np.float64)
+    m[0, 0] = f / aspect
+    m[1, 1] = -f
+    m[2, 2] = far / (near - far)
+    m[2, 3] = -1.0
+    m[3, 2] = near * far / (near - far)
+    return m
+
+
+def make_sphere_mesh(segments: int = 32, rings: int = 16):
+    """A unit UV sphere with the reference light volume's topology (assets/models/sphere: 32 segments,
+    16 rings, 960 triangles), counter-clockwise seen from outside.  Returns (verts [n,3] f32, indices [960,3] u32)."""
+    verts = [(0.0, 1.0, 0.0)]
+    for r in range(1, rings):
+        th = np.pi * r / rings
+        for s_ in range(segments):
+            ph = 2.0 * np.pi * s_ / segments
+            verts.append((np.sin(th) * np.cos(ph), np.cos(th), np.sin(th) * np.sin(ph)))
+    verts.append((0.0, -1.0, 0.0))
+    ring = lambda r, s_: 1 + (r - 1) * segments + s_ % segments
+    south = len(verts) - 1
+    tris = []
+    for s_ in range(segments):
+        tris.append((0, ring(1, s_ + 1), ring(1, s_)))
+        tris.append((south, ring(rings - 1, s_), ring(rings - 1, s_ + 1)))
+    for r in range(1, rings - 1):
+        for s_ in range(segments):
+            a, b, c, d = ring(r, s_), ring(r, s_ + 1), ring(r + 1, s_), ring(r + 1, s_ + 1)
+            tris.append((a, b, d))
+            tris.append((a, d, c))
+    v = np.asarray(verts, dtype=np.float32)
+    t = np.asarray(tris, dtype=np.uint32)
+    # orientation check: normals of counter-clockwise triangles point away from the centre
+    n = np.cross(v[t[:, 1]] - v[t[:, 0]], v[t[:, 2]] - v[t[:, 0]])
+    flip = (n * (v[t[:, 0]] + v[t[:, 1]] + v[t[:, 2]])).sum(-1) < 0
+    t[flip] = t[flip][:, [0, 2, 1]]
+    return v, t
+
+
 def default_scene_info() -> np.ndarray:
     """SceneInfo of the reference's demo frame (Program.cs:84,120-132)."""
     s = np.zeros((), dtype=SCENE_DTYPE)
     cam = (2.0, 1.0, -4.0)
     s["camera_view"] = look_at(cam, (0, 0, 0), (0, 1, 0)).astype(np.float32).ravel()
-    s["camera_projection"] = np.eye(4, dtype=np.float32).ravel()  # not read by the shading path
+    s["camera_projection"] = perspective(60.0, 16.0 / 9.0, 0.1, 100.0).astype(np.float32).ravel()  # Camera.cs:12,30-35
     s["camera_position"] = cam
     s["dir_light_direction"] = (2.0, -4.0, 1.0)
     s["dir_light_color"] = (0.35, 0.25, 0.2)
