@@ -113,6 +113,53 @@ def time_ibl(device) -> dict:
                       "prefilter 128^2 x5 mips, LUT 512^2"}
 
 
+def time_coverage(f, dev_frame, renderer, device) -> dict:
+    """Light-volume coverage (VKR_COVERAGE_MESH) at the benchmark size: the mask kernel, and the shading kernel
+    consuming the masks.  With the reference's light radii every volume contains the camera, so every mask
+    bit is set and the image is the full-coverage one; a second scene shrinks the volumes to show what the
+    per-light masks save when lights are local."""
+    import dataclasses
+    import torch
+    from vulkanrenderer_amd import passes as P, synth
+
+    verts, tris = synth.make_sphere_mesh()
+    dverts, dtris = torch.from_numpy(verts).to(device), torch.from_numpy(tris.astype(np.int32)).to(device)
+
+    def timed(fn, reps=5):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    out = {}
+    want = renderer.color.clone()
+    masked = dataclasses.replace(dev_frame, coverage=P.light_coverage(dev_frame, dverts, dtris))
+    color, thr = torch.empty_like(renderer.color), torch.empty_like(renderer.threshold)
+    out["reference_radii"] = {"coverage_ms": round(timed(lambda: P.light_coverage(dev_frame, dverts, dtris)), 4),
+                              "shade_ms": round(timed(lambda: P.shade(masked, color, thr)), 4),
+                              "covered_fraction": 1.0 if bool((masked.coverage == -1).all()) else None,
+                              "equals_full_coverage_image": bool(torch.equal(color, want))}
+    lights = f.lights.copy()
+    for i in range(len(lights)):
+        lights["color"][i] *= 0.02
+        r = synth.light_volume_radius(lights["color"][i])
+        m = np.diag([r, r, r, 1.0]); m[3, :3] = lights["position"][i]
+        lights["model"][i] = m.astype(np.float32).ravel()
+    small = dataclasses.replace(dev_frame, lights=torch.from_numpy(np.frombuffer(lights.tobytes(), dtype=np.uint8).copy()).to(device))
+    small.coverage = P.light_coverage(small, dverts, dtris)
+    bits = small.coverage.view(torch.uint8)
+    frac = float(sum(int(((bits >> k) & 1).sum()) for k in range(8))) / (len(lights) * f.width * f.height)
+    out["local_lights"] = {"coverage_ms": round(timed(lambda: P.light_coverage(small, dverts, dtris)), 4),
+                           "shade_ms": round(timed(lambda: P.shade(small, color, thr)), 4),
+                           "covered_fraction": round(frac, 4),
+                           "note": "same lights with colours x0.02: volume radius 16*sqrt(max/5) shrinks to ~1-2.5 units"}
+    out["mesh"] = f"UV sphere, {len(verts)} vertices, {len(tris)} triangles (the reference volume's topology)"
+    return out
+
+
 def measured_traffic(lights: int, cube_res: int, dir_res: int) -> dict:
     """HBM-side bytes per launch from the committed rocprofv3 counter passes (profiles/r1_traffic.json);
     counters cannot be read from inside this process, so the figures apply only to the workload they
@@ -157,6 +204,7 @@ def main() -> None:
     ap.add_argument("--dir-res", type=int, default=DIR_RES)
     ap.add_argument("--cpu-rows", type=int, default=HEIGHT, help="rows of the frame the CPU baseline shades (0 = skip)")
     ap.add_argument("--no-ibl", action="store_true", help="skip the IBL precompute timing")
+    ap.add_argument("--no-coverage", action="store_true", help="skip the light-volume coverage timing")
     args = ap.parse_args()
 
     import torch
@@ -281,6 +329,8 @@ def main() -> None:
                                  "shade_frac_of_measured": round(shade_tflops / fp32.value, 4),
                                  "bloom_h_frac_of_measured": round(16 * px / (kernel_ms["bloom_h"] * 1e-3) / 1e9 / copy.value, 4),
                                  "bloom_v_frac_of_measured": round(20 * px / (kernel_ms["bloomv_post"] * 1e-3) / 1e9 / copy.value, 4)}
+    if world == 1 and not args.no_coverage:
+        out["light_volume_coverage"] = time_coverage(f, dev_frame, renderer, device)
     if not args.no_ibl:
         out["ibl_precompute"] = time_ibl(device)
     if world == 1 and args.cpu_rows > 0:

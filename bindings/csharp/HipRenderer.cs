@@ -29,6 +29,7 @@ internal static unsafe class Native
     [DllImport(Lib)] public static extern int vkr_resize(nint ctx, int width, int height);
     [DllImport(Lib)] public static extern int vkr_update_scene_info(nint ctx, in SceneInfo info);
     [DllImport(Lib)] public static extern int vkr_set_lights(nint ctx, LightInfo* lights, int n, int coverageMode);
+    [DllImport(Lib)] public static extern int vkr_set_light_volume_mesh(nint ctx, float* verts, int nVerts, uint* indices, int nTris);
     [DllImport(Lib)] public static extern int vkr_begin_frame(nint ctx);
     [DllImport(Lib)] public static extern int vkr_end_frame(nint ctx);
     [DllImport(Lib)] public static extern int vkr_upload_gbuffer(nint ctx, void* albedo, void* normal, void* arm, void* position);
@@ -48,6 +49,7 @@ public sealed unsafe class HipRenderer : IDisposable
 {
     nint ctx;
     bool disposedValue;
+    bool hasVolumeMesh;
     public List<Light> Lights = new();   // VulkanRenderer.cs:65
 
     public HipRenderer(in VkrConfig config) => Check(Native.vkr_create(config, out ctx));
@@ -65,8 +67,15 @@ public sealed unsafe class HipRenderer : IDisposable
     {
         var infos = stackalloc LightInfo[Lights.Count];
         for (int i = 0; i < Lights.Count; i++) infos[i] = Lights[i].ToInfo();   // Light.cs:10
-        Check(Native.vkr_set_lights(ctx, infos, Lights.Count, 0));
+        Check(Native.vkr_set_lights(ctx, infos, Lights.Count, hasVolumeMesh ? 1 : 0));   // 1 = VKR_COVERAGE_MESH
         Check(Native.vkr_end_frame(ctx));
+    }
+
+    // sphereMesh of the reference (VulkanRenderer.cs:78,269): positions and indices of the light volume
+    public void SetLightVolumeMesh(float* verts, int nVerts, uint* indices, int nTris)
+    {
+        Check(Native.vkr_set_light_volume_mesh(ctx, verts, nVerts, indices, nTris));
+        hasVolumeMesh = true;
     }
 
     public void WaitIdle() => Check(Native.vkr_sync(ctx));

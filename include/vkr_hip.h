@@ -240,6 +240,9 @@ VKR_EXPORT int32_t vkr_resize(vkr_ctx *ctx, int32_t width, int32_t height);   /*
 
 VKR_EXPORT int32_t vkr_update_scene_info(vkr_ctx *ctx, const VkrSceneInfo *info);               /* UpdateSceneInfo, :635-646 */
 VKR_EXPORT int32_t vkr_set_lights(vkr_ctx *ctx, const VkrLightInfo *lights, int32_t n, int32_t coverage_mode); /* Lights, :65 */
+/* The mesh every light volume is an instance of (the reference loads assets/models/sphere/sphere.glb, a unit
+ * sphere of 559 vertices / 960 triangles, VulkanRenderer.cs:78,269); needed for VKR_COVERAGE_MESH. */
+VKR_EXPORT int32_t vkr_set_light_volume_mesh(vkr_ctx *ctx, const float *verts, int32_t n_verts, const uint32_t *indices, int32_t n_tris);
 VKR_EXPORT int32_t vkr_begin_frame(vkr_ctx *ctx);                                                /* BeginFrame, :286-318 */
 /* EndFrame, :320-623: composition pass, bloom 1, bloom 2, post-process, then advances the frame index. */
 VKR_EXPORT int32_t vkr_end_frame(vkr_ctx *ctx);

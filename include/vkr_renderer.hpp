@@ -78,8 +78,15 @@ public:
         std::vector<VkrLightInfo> infos;
         infos.reserve(Lights.size());
         for (const Light &l : Lights) infos.push_back(l.ToInfo());
-        check(vkr_set_lights(ctx_, infos.data(), (int32_t)infos.size(), VKR_COVERAGE_FULLSCREEN));
+        check(vkr_set_lights(ctx_, infos.data(), (int32_t)infos.size(), has_volume_mesh_ ? VKR_COVERAGE_MESH : VKR_COVERAGE_FULLSCREEN));
         check(vkr_end_frame(ctx_));
+    }
+    // The reference's sphereMesh (VulkanRenderer.cs:78,269): once set, each light's draw touches only the
+    // pixels its volume covers, as the reference's rasterised volumes do.
+    void SetLightVolumeMesh(const float *verts, int32_t n_verts, const uint32_t *indices, int32_t n_tris)
+    {
+        check(vkr_set_light_volume_mesh(ctx_, verts, n_verts, indices, n_tris));
+        has_volume_mesh_ = true;
     }
     void WaitIdle() { check(vkr_sync(ctx_)); }
     void Resize(int32_t width, int32_t height) { check(vkr_resize(ctx_, width, height)); }  // RecreateSwapchain
@@ -111,6 +118,7 @@ public:
 
 private:
     vkr_ctx *ctx_ = nullptr;
+    bool has_volume_mesh_ = false;
 };
 
 }  // namespace vkr

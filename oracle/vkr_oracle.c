@@ -663,15 +663,29 @@ ORC_API void orc_light_coverage(const orc_coverage_args *a)
                 for (int i = 0; i < 3 && !reject; i++) /* an edge with all four corners outside rules the block out */
                     reject = cov_edge(tri, i, xa, ya) < 0.0 && cov_edge(tri, i, xb, ya) < 0.0 && cov_edge(tri, i, xa, yb) < 0.0 && cov_edge(tri, i, xb, yb) < 0.0;
                 if (reject) continue;
-                for (int y = by0; y < by1; y++) {
-                    const double yn = fma((double)(a->row0 + y) + 0.5, sy, -1.0);
-                    for (int x = bx0; x < bx1; x++) {
-                        uint64_t *m = masks + (size_t)(y / 8) * tiles_x + x / 8;
-                        const uint64_t bit = 1ull << ((y & 7) * 8 + (x & 7));
-                        if (*m & bit) continue;
-                        if (cov_inside(tri, fma((double)x + 0.5, sx, -1.0), yn)) *m |= bit;
+                /* per 8x8 tile: the same corner test drops the tile, four covered corners fill it
+                 * (both follow from the edge functions and the depth being linear over the tile),
+                 * only the remaining tiles are tested pixel by pixel */
+                for (int ty0 = by0; ty0 < by1; ty0 += 8)
+                    for (int tx0 = bx0; tx0 < bx1; tx0 += 8) {
+                        const int tx1 = tx0 + 8 < bx1 ? tx0 + 8 : bx1, ty1 = ty0 + 8 < by1 ? ty0 + 8 : by1;
+                        uint64_t *m = masks + (size_t)(ty0 / 8) * tiles_x + tx0 / 8;
+                        const double cx[2] = {fma((double)tx0 + 0.5, sx, -1.0), fma((double)(tx1 - 1) + 0.5, sx, -1.0)};
+                        const double cy[2] = {fma((double)(a->row0 + ty0) + 0.5, sy, -1.0), fma((double)(a->row0 + ty1 - 1) + 0.5, sy, -1.0)};
+                        int drop = 0;
+                        for (int i = 0; i < 3 && !drop; i++)
+                            drop = cov_edge(tri, i, cx[0], cy[0]) < 0.0 && cov_edge(tri, i, cx[1], cy[0]) < 0.0 && cov_edge(tri, i, cx[0], cy[1]) < 0.0 && cov_edge(tri, i, cx[1], cy[1]) < 0.0;
+                        if (drop) continue;
+                        const int fill = cov_inside(tri, cx[0], cy[0]) && cov_inside(tri, cx[1], cy[0]) && cov_inside(tri, cx[0], cy[1]) && cov_inside(tri, cx[1], cy[1]);
+                        for (int y = ty0; y < ty1; y++) {
+                            const double yn = fma((double)(a->row0 + y) + 0.5, sy, -1.0);
+                            for (int x = tx0; x < tx1; x++) {
+                                const uint64_t bit = 1ull << ((y & 7) * 8 + (x & 7));
+                                if (*m & bit) continue;
+                                if (fill || cov_inside(tri, fma((double)x + 0.5, sx, -1.0), yn)) *m |= bit;
+                            }
+                        }
                     }
-                }
             }
         }
     }

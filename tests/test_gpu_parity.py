@@ -484,3 +484,39 @@ def test_shade_with_light_volume_coverage(gpu, oracle):
     assert_bits_equal(P.f16_bits(color), want_c, "composition colour with light-volume coverage")
     assert_bits_equal(P.f16_bits(thr), want_t, "thresholded colour with light-volume coverage")
     assert not np.array_equal(want_c, oracle.shade(f)[0])  # the masks do change the image
+
+
+def test_renderer_with_light_volume_mesh(gpu, oracle):
+    """Layer 2 with VKR_COVERAGE_MESH: SetLightVolumeMesh + small volumes, EndFrame equals the oracle
+    chain shaded under the oracle's masks; order errors without a mesh."""
+    from vulkanrenderer_amd.renderer import HipRenderer
+    w, h, nl = 136, 88, 5
+    verts, tris = synth.make_sphere_mesh()
+    f = synth.make_frame(71, w, h, nl, 16, 64, irr_res=8, pref_res=16, lut_res=32)
+    f.scene = _camera_scene((2.0, 1.0, -4.0), aspect=w / h)
+    f.lights = _small_lights(np.random.default_rng(3), nl, 0.03)
+    masks = oracle.light_coverage(f.scene, f.lights, verts, tris, w, h)
+    with HipRenderer(w, h, max_lights=8, dir_shadow_res=64, point_shadow_res=16, env_res=16,
+                     irradiance_res=8, prefilter_res=16, prefilter_mips=1, brdf_lut_res=32) as r:
+        r.UploadEnvironmentCubemap(synth.make_env_cube(np.random.default_rng(2), 16))
+        r.CreateIrradianceCubemap(); r.CreatePrefilteredCubemap(); r.CreateBRDFLUTTexture()
+        f.irradiance = r.Read(_lib.TARGET_IRRADIANCE)
+        f.prefilter = r.Read(_lib.TARGET_PREFILTER, mip=0)
+        f.brdf_lut = r.Read(_lib.TARGET_BRDF_LUT)
+        with pytest.raises(_lib.VkrError):
+            r.SetLightInfos(f.lights, _lib.COVERAGE_MESH)   # no mesh yet
+        bad = tris.copy(); bad[5, 1] = len(verts)
+        with pytest.raises(_lib.VkrError):
+            r.SetLightVolumeMesh(verts, bad)               # index past the vertex array
+        r.SetLightVolumeMesh(verts, tris)
+        r.UpdateSceneInfo(f.scene)
+        r.UploadGBuffer(f.albedo, f.normal, f.arm, f.position)
+        r.UploadDirectionalShadowMap(f.dir_shadow)
+        for i in range(nl):
+            r.UploadPointShadowMap(i, f.cube_shadow[i])
+        r.SetLightInfos(f.lights, _lib.COVERAGE_MESH)
+        r.BeginFrame()
+        r._call(r._lib.vkr_end_frame)
+        want_c, want_t = oracle.shade(f, coverage=masks)
+        assert_bits_equal(r.Read(_lib.TARGET_COLOR, 0), want_c, "colour")
+        assert_bits_equal(r.Read(_lib.TARGET_THRESHOLD, 0), want_t, "threshold")

@@ -117,6 +117,7 @@ PROTOTYPES = {
     "vkr_resize": [_vp, _i32, _i32],
     "vkr_update_scene_info": [_vp, C.POINTER(SceneInfo)],
     "vkr_set_lights": [_vp, _vp, _i32, _i32],
+    "vkr_set_light_volume_mesh": [_vp, _vp, _i32, _vp, _i32],
     "vkr_begin_frame": [_vp],
     "vkr_end_frame": [_vp],
     "vkr_current_frame": [_vp],

@@ -32,6 +32,7 @@ struct Frame {
     int coverage = VKR_COVERAGE_FULLSCREEN;
     VkrSceneInfo scene;
     void *color = nullptr, *threshold = nullptr, *bloom1 = nullptr, *bloom2 = nullptr, *ldr = nullptr;
+    uint64_t *coverage_buf = nullptr;  // light-volume masks, max_lights * tiles
     bool bloom2_valid = false;
 };
 
@@ -48,6 +49,9 @@ struct vkr_ctx {
     bool have_env = false, have_irr = false, have_pref = false, have_lut = false;
     void *env_tiled = nullptr;      // the environment cube as 4x4-texel tiles (what the IBL passes sample)
     float *cube_staging = nullptr;  // one linear depth cube on its way into the tiled storage
+    float *mesh_verts = nullptr;    // light-volume mesh (vkr_set_light_volume_mesh)
+    uint32_t *mesh_indices = nullptr;
+    int mesh_n_verts = 0, mesh_n_tris = 0;
     bool cubes_tiled = false;       // point shadow cubes are stored VKR_CUBE_LAYOUT_TILED_8X4
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timing_valid = false;
@@ -62,7 +66,7 @@ static void free_frame_sized(vkr_ctx *c)
 {
     for (Frame &f : c->frames) {
         for (void *&g : f.gbuf) { if (g) (void)hipFree(g); g = nullptr; }
-        void **imgs[] = {&f.background, &f.color, &f.threshold, &f.bloom1, &f.bloom2, &f.ldr};
+        void **imgs[] = {&f.background, &f.color, &f.threshold, &f.bloom1, &f.bloom2, &f.ldr, (void **)&f.coverage_buf};
         for (void **p : imgs) { if (*p) (void)hipFree(*p); *p = nullptr; }
         f.has_background = false;
         f.bloom2_valid = false;
@@ -80,6 +84,8 @@ static int32_t alloc_frame_sized(vkr_ctx *c)
         VKR_HIP_CHECK(hipMalloc(&f.bloom1, img));
         VKR_HIP_CHECK(hipMalloc(&f.bloom2, img));
         VKR_HIP_CHECK(hipMalloc(&f.ldr, (size_t)c->cfg.width * c->cfg.height * 4));
+        const size_t tiles = (size_t)((c->cfg.width + 7) / 8) * ((c->cfg.height + 7) / 8);
+        VKR_HIP_CHECK(hipMalloc((void **)&f.coverage_buf, (size_t)c->cfg.max_lights * tiles * sizeof(uint64_t)));
     }
     return VKR_OK;
 }
@@ -95,13 +101,15 @@ static void destroy(vkr_ctx *c)
         if (f.cube_shadow) (void)hipFree(f.cube_shadow);
         if (f.lights) (void)hipFree(f.lights);
     }
-    void *ibl[] = {c->env, c->env_tiled, c->irradiance, c->brdf_lut, c->cube_staging};
+    void *ibl[] = {c->env, c->env_tiled, c->irradiance, c->brdf_lut, c->cube_staging, c->mesh_verts, c->mesh_indices};
     for (void *p : ibl) if (p) (void)hipFree(p);
     for (void *p : c->prefilter) if (p) (void)hipFree(p);
     for (hipEvent_t e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
+
+static int32_t run_coverage(vkr_ctx *c, Frame &f);
 
 #define VKR_CTX(c)                                                   \
     VKR_REQUIRE((c) != nullptr, "%s: context is null", __func__);    \
@@ -124,7 +132,24 @@ static int32_t fill_shade_args(vkr_ctx *c, Frame &f, VkrShadeArgs &a)
     a.prefilter = c->prefilter[0]; a.pref_res = c->cfg.prefilter_res;
     a.brdf_lut = c->brdf_lut; a.lut_res = c->cfg.brdf_lut_res;
     a.out_color = f.color; a.out_threshold = f.threshold;
+    a.coverage_masks = f.coverage == VKR_COVERAGE_MESH ? f.coverage_buf : nullptr;
     return VKR_OK;
+}
+
+// The light-volume draws' coverage (what rasterising sphere.glb per light decides in the reference).
+static int32_t run_coverage(vkr_ctx *c, Frame &f)
+{
+    if (f.coverage != VKR_COVERAGE_MESH || f.n_lights == 0) return VKR_OK;
+    if (!c->mesh_verts) return fail(VKR_ERR_ORDER, "VKR_COVERAGE_MESH needs a light-volume mesh: call vkr_set_light_volume_mesh first");
+    VkrCoverageArgs a;
+    memset(&a, 0, sizeof(a));
+    a.width = c->cfg.width; a.rows = c->cfg.height; a.frame_rows = c->cfg.height; a.row0 = 0;
+    a.scene = f.scene;
+    a.lights = f.lights; a.n_lights = f.n_lights;
+    a.verts = c->mesh_verts; a.n_verts = c->mesh_n_verts;
+    a.indices = c->mesh_indices; a.n_tris = c->mesh_n_tris;
+    a.masks = f.coverage_buf;
+    return vkr_light_coverage(&a, c->stream);
 }
 
 static VkrBloomArgs bloom_args(vkr_ctx *c, Frame &f, int horizontal)
@@ -252,7 +277,8 @@ extern "C" int32_t vkr_set_lights(vkr_ctx *c, const VkrLightInfo *lights, int32_
     VKR_CTX(c);
     VKR_REQUIRE(n >= 0 && n <= c->cfg.max_lights, "vkr_set_lights: %d lights outside [0,%d]", n, c->cfg.max_lights);
     VKR_REQUIRE(n == 0 || lights != nullptr, "vkr_set_lights: lights is null");
-    if (coverage_mode != VKR_COVERAGE_FULLSCREEN) return fail(VKR_ERR_UNSUPPORTED, "vkr_set_lights: coverage mode %d is not implemented", coverage_mode);
+    VKR_REQUIRE(coverage_mode == VKR_COVERAGE_FULLSCREEN || coverage_mode == VKR_COVERAGE_MESH, "vkr_set_lights: unknown coverage mode %d", coverage_mode);
+    if (coverage_mode == VKR_COVERAGE_MESH && !c->mesh_verts) return fail(VKR_ERR_ORDER, "vkr_set_lights: VKR_COVERAGE_MESH needs a light-volume mesh (vkr_set_light_volume_mesh)");
     Frame &f = c->frames[c->frame];
     if (n) {
         VKR_HIP_CHECK(hipMemcpyAsync(f.lights, lights, (size_t)n * sizeof(VkrLightInfo), hipMemcpyHostToDevice, c->stream));
@@ -280,6 +306,25 @@ static int32_t upload(vkr_ctx *c, void *dst, const void *src, size_t bytes)
 {
     VKR_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     VKR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return VKR_OK;
+}
+
+extern "C" int32_t vkr_set_light_volume_mesh(vkr_ctx *c, const float *verts, int32_t n_verts, const uint32_t *indices, int32_t n_tris)
+{
+    VKR_CTX(c);
+    VKR_REQUIRE(verts && indices && n_verts > 0 && n_tris > 0, "vkr_set_light_volume_mesh: mesh missing");
+    VKR_REQUIRE(n_verts <= 1024, "vkr_set_light_volume_mesh: %d vertices; at most 1024 are supported", n_verts);
+    for (int64_t i = 0; i < (int64_t)n_tris * 3; i++)
+        VKR_REQUIRE(indices[i] < (uint32_t)n_verts, "vkr_set_light_volume_mesh: index %u at %lld is outside the %d vertices", indices[i], (long long)i, n_verts);
+    VKR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->mesh_verts) { (void)hipFree(c->mesh_verts); c->mesh_verts = nullptr; }
+    if (c->mesh_indices) { (void)hipFree(c->mesh_indices); c->mesh_indices = nullptr; }
+    VKR_HIP_CHECK(hipMalloc((void **)&c->mesh_verts, (size_t)n_verts * 12));
+    VKR_HIP_CHECK(hipMalloc((void **)&c->mesh_indices, (size_t)n_tris * 12));
+    int32_t rc = upload(c, c->mesh_verts, verts, (size_t)n_verts * 12);
+    if (rc == VKR_OK) rc = upload(c, c->mesh_indices, indices, (size_t)n_tris * 12);
+    if (rc != VKR_OK) return rc;
+    c->mesh_n_verts = n_verts; c->mesh_n_tris = n_tris;
     return VKR_OK;
 }
 
@@ -407,6 +452,7 @@ extern "C" int32_t vkr_pass_composition(vkr_ctx *c)
     VkrShadeArgs a;
     int32_t rc = fill_shade_args(c, c->frames[c->frame], a);
     if (rc != VKR_OK) return rc;
+    if ((rc = run_coverage(c, c->frames[c->frame])) != VKR_OK) return rc;
     return vkr_shade(&a, c->stream);
 }
 
@@ -437,6 +483,7 @@ extern "C" int32_t vkr_end_frame(vkr_ctx *c)
     int32_t rc = fill_shade_args(c, f, a);
     if (rc != VKR_OK) return rc;
     VKR_HIP_CHECK(hipEventRecord(c->ev[0], c->stream));
+    if ((rc = run_coverage(c, f)) != VKR_OK) return rc;  // counted with the composition pass, whose draws it stands for
     if ((rc = vkr_shade(&a, c->stream)) != VKR_OK) return rc;
     VKR_HIP_CHECK(hipEventRecord(c->ev[1], c->stream));
     VkrBloomArgs b1 = bloom_args(c, f, 1);

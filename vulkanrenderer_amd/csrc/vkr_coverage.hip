@@ -103,13 +103,45 @@ __global__ __launch_bounds__(256) void coverage_kernel(const CoverageParams p)
         }
         __syncthreads();
         const int count = s_count;
+        // tile `lane` of this wave (for the per-tile corner test below)
+        const int ktile = wave * 64 + lane;
+        const int kx0 = bx0 + (ktile & 15) * 8, ky0 = by0 + (ktile >> 4) * 8;
+        const int kx1 = min(kx0 + 8, bx1), ky1 = min(ky0 + 8, by1);
+        const bool ktile_in_image = kx0 < bx1 && ky0 < by1;
+        const double cxa = __builtin_fma((double)kx0 + 0.5, sx, -1.0), cxb = __builtin_fma((double)(kx1 - 1) + 0.5, sx, -1.0);
+        const double cya = __builtin_fma((double)(p.row0 + ky0) + 0.5, sy, -1.0), cyb = __builtin_fma((double)(p.row0 + ky1 - 1) + 0.5, sy, -1.0);
         for (int e = 0; e < count; e++) {
             const CovTri &tr = s_tri[e];
-            for (int k = 0; k < 64; k++) {
+            // lane = tile: the corner test drops the tile, four covered corners fill it (the edge
+            // functions and the depth are linear over the tile); the rest is tested per pixel
+            bool drop = !ktile_in_image, fill = ktile_in_image;
+            {
+                bool in[4] = {true, true, true, true};
+                double es[4][3];
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    es[0][i] = cov_edge(tr, i, cxa, cya); es[1][i] = cov_edge(tr, i, cxb, cya);
+                    es[2][i] = cov_edge(tr, i, cxa, cyb); es[3][i] = cov_edge(tr, i, cxb, cyb);
+                    drop = drop || (es[0][i] < 0.0 && es[1][i] < 0.0 && es[2][i] < 0.0 && es[3][i] < 0.0);
+#pragma unroll
+                    for (int c = 0; c < 4; c++) in[c] = in[c] && es[c][i] >= 0.0;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const double zs = __builtin_fma(es[c][2], tr.z[2], __builtin_fma(es[c][1], tr.z[1], es[c][0] * tr.z[0]));
+                    fill = fill && in[c] && (es[c][0] + es[c][1]) + es[c][2] > 0.0 && zs >= 0.0 && zs <= tr.D;
+                }
+            }
+            fill = fill && !drop;
+            covered |= __ballot(fill);  // lane = pixel again: every pixel of a filled tile (pixels outside the image are masked at the end)
+            unsigned long long partial = __ballot(!drop && !fill);
+            while (partial) {  // wave-uniform walk over the tiles that need per-pixel tests
+                const int k = __builtin_ctzll(partial);
+                partial &= partial - 1;
                 const int tile = wave * 64 + k;
                 const int x = bx0 + (tile & 15) * 8 + lx, y = by0 + (tile >> 4) * 8 + ly;
                 const bool todo = x < bx1 && y < by1 && !((covered >> k) & 1ull);
-                if (!__any(todo)) continue;  // wave-uniform: tile outside the image or already full
+                if (!__any(todo)) continue;
                 const double xn = __builtin_fma((double)x + 0.5, sx, -1.0), yn = __builtin_fma((double)(p.row0 + y) + 0.5, sy, -1.0);
                 const double e0 = cov_edge(tr, 0, xn, yn), e1 = cov_edge(tr, 1, xn, yn), e2 = cov_edge(tr, 2, xn, yn);
                 bool in = todo && e0 >= 0.0 && e1 >= 0.0 && e2 >= 0.0 && (e0 + e1) + e2 > 0.0;
@@ -128,7 +160,8 @@ __global__ __launch_bounds__(256) void coverage_kernel(const CoverageParams p)
         const int tile = wave * 64 + k;
         const int tx = (bx0 >> 3) + (tile & 15), ty = (by0 >> 3) + (tile >> 4);
         if (tx >= p.tiles_x || ty >= p.tiles_y) continue;
-        const unsigned long long m = __ballot((covered >> k) & 1ull);
+        const int x = bx0 + (tile & 15) * 8 + lx, y = by0 + (tile >> 4) * 8 + ly;
+        const unsigned long long m = __ballot(((covered >> k) & 1ull) && x < bx1 && y < by1);
         if (lane == 0) masks[(size_t)ty * p.tiles_x + tx] = m;
     }
 }

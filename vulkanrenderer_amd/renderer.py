@@ -121,10 +121,17 @@ class HipRenderer:
             infos[i] = light.ToInfo()
         self.SetLightInfos(infos)
 
-    def SetLightInfos(self, infos: np.ndarray) -> None:
+    def SetLightInfos(self, infos: np.ndarray, coverage: int = _lib.COVERAGE_FULLSCREEN) -> None:
         assert infos.dtype == LIGHT_DTYPE
         infos = np.ascontiguousarray(infos)
-        self._call(self._lib.vkr_set_lights, _host_ptr(infos) if len(infos) else C.c_void_p(0), len(infos), _lib.COVERAGE_FULLSCREEN)
+        self._call(self._lib.vkr_set_lights, _host_ptr(infos) if len(infos) else C.c_void_p(0), len(infos), coverage)
+
+    def SetLightVolumeMesh(self, verts: np.ndarray, triangles: np.ndarray) -> None:
+        """The mesh each light volume is an instance of (the reference's sphereMesh, VulkanRenderer.cs:78,269);
+        with it, SetLightInfos(..., COVERAGE_MESH) restricts each light's draw to the pixels its volume covers."""
+        verts = np.ascontiguousarray(verts, dtype=np.float32)
+        triangles = np.ascontiguousarray(triangles, dtype=np.uint32)
+        self._call(self._lib.vkr_set_light_volume_mesh, _host_ptr(verts), len(verts), _host_ptr(triangles), len(triangles))
 
     def WaitIdle(self) -> None:
         self._call(self._lib.vkr_sync)
