@@ -80,3 +80,16 @@ def test_ibl_shaders(oracle):
     n = g["brdf_lut"].shape[0]
     lut = oracle.f16_to_f32(oracle.brdf_lut(n))
     assert close(lut, g["brdf_lut"]).all(), np.abs(lut - g["brdf_lut"]).max()
+
+
+def test_light_volume_vertex_shader(oracle):
+    """light.vert.spv: gl_Position = proj * view * model * vec4(pos, 1) -- the transform the light-volume
+    coverage starts from.  Products are associated as the shader does ((proj * view) * model), so the
+    oracle agrees with the recorded positions to a few binary32 ulps."""
+    g = np.load(os.path.join(GOLDEN, "light_vert.npz"))
+    scene, lights, verts, want = g["scene"][()], g["lights"], g["verts"], g["gl_position"]
+    for li in range(len(lights)):
+        for vi in range(len(verts)):
+            got = oracle.light_clip_vertex(scene, lights[li:li + 1], verts[vi])
+            scale = np.abs(want[li, vi]).max()
+            assert np.abs(got - want[li, vi]).max() <= 4 * np.spacing(np.float32(scale)), (li, vi, got, want[li, vi])

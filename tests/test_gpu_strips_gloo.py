@@ -18,7 +18,20 @@ def _frame():
     return synth.make_frame(91, W, H, LIGHTS, 32, 128, irr_res=8, pref_res=16, lut_res=32)
 
 
-def _worker(rank, world, port, out_path):
+def _local_light_frame():
+    f = _frame()
+    f.scene = f.scene.copy()
+    f.scene["camera_projection"] = synth.perspective(60.0, W / H, 0.1, 100.0).astype(np.float32).ravel()
+    f.lights = f.lights.copy()
+    for i in range(len(f.lights)):
+        f.lights["color"][i] *= 0.03
+        r = synth.light_volume_radius(f.lights["color"][i])
+        m = np.diag([r, r, r, 1.0]); m[3, :3] = f.lights["position"][i]
+        f.lights["model"][i] = m.astype(np.float32).ravel()
+    return f
+
+
+def _worker(rank, world, port, out_path, with_mesh=False):
     import torch
     import torch.distributed as dist
     from vulkanrenderer_amd import passes as P
@@ -27,10 +40,14 @@ def _worker(rank, world, port, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         dev = torch.device("cuda", 0)
-        f = _frame()
+        f = _local_light_frame() if with_mesh else _frame()
         plan = StripPlan.make(rank, world, H)
         r = StripRenderer(plan, W, device=dev)
-        r.render(P.DeviceFrame.upload(f.rows(plan.row0, plan.row0 + plan.rows), dev))
+        mesh = None
+        if with_mesh:
+            verts, tris = synth.make_sphere_mesh()
+            mesh = (torch.from_numpy(verts).to(dev), torch.from_numpy(tris.astype(np.int32)).to(dev))
+        r.render(P.DeviceFrame.upload(f.rows(plan.row0, plan.row0 + plan.rows), dev), mesh)
         parts = r.gather(0)
         if rank == 0:
             np.save(out_path, torch.cat([p.cpu() for p in parts], 0).numpy())
@@ -60,3 +77,20 @@ def test_hip_strips_over_gloo_equal_single_rank(gpu, oracle, world, tmp_path):
     assert np.array_equal(got, want)
     ref = oracle.frame_chain(f)["ldr"]
     assert np.abs(got.astype(np.int32) - ref.astype(np.int32)).max() <= 1
+
+
+def test_hip_strips_with_light_volume_coverage(gpu, oracle, tmp_path):
+    """Three ranks, each rasterising the light volumes for its own rows: the assembled image is the
+    oracle's image under the whole-frame masks (8-bit, within 1 LSB)."""
+    import torch.multiprocessing as mp
+    f = _local_light_frame()
+    verts, tris = synth.make_sphere_mesh()
+    masks = oracle.light_coverage(f.scene, f.lights, verts, tris, W, H)
+    color, thr = oracle.shade(f, coverage=masks)
+    b2 = oracle.bloom_blur(oracle.bloom_blur(thr, True, oracle.WRAP_REPEAT), False, oracle.WRAP_CLAMP)
+    want = oracle.postprocess(color, b2)
+    out_path = str(tmp_path / "ldr.npy")
+    mp.spawn(_worker, args=(3, _free_port(), out_path, True), nprocs=3, join=True)
+    got = np.load(out_path)
+    assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
+    assert not np.array_equal(want, oracle.frame_chain(f)["ldr"])  # the masks matter for this frame

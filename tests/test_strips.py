@@ -31,9 +31,15 @@ class OracleBackend:
 
     def shade(self, frame, color, thr):
         from tests import oracle
-        c, t = oracle.shade(frame)
+        c, t = oracle.shade(frame, coverage=getattr(frame, "coverage_masks", None))
         self._bits(color)[...] = c
         self._bits(thr)[...] = t
+
+    def with_coverage(self, frame, volume_mesh, frame_rows, row0):
+        from tests import oracle
+        verts, tris = volume_mesh
+        frame.coverage_masks = oracle.light_coverage(frame.scene, frame.lights, verts, tris, frame.width, frame.height, frame_rows, row0)
+        return frame
 
     def bloom_h(self, thr, bloom1, rows):
         from tests import oracle
@@ -54,14 +60,28 @@ def _frame():
     return synth.make_frame(77, W, H, LIGHTS, 16, 64, irr_res=4, pref_res=8, lut_res=16)
 
 
-def _worker(rank, world, port, out_path):
+def _local_light_frame():
+    """The frame with small light volumes and a real camera, so that coverage differs from pixel to pixel."""
+    f = _frame()
+    f.scene = f.scene.copy()
+    f.scene["camera_projection"] = synth.perspective(60.0, W / H, 0.1, 100.0).astype(np.float32).ravel()
+    f.lights = f.lights.copy()
+    for i in range(len(f.lights)):
+        f.lights["color"][i] *= 0.03
+        r = synth.light_volume_radius(f.lights["color"][i])
+        m = np.diag([r, r, r, 1.0]); m[3, :3] = f.lights["position"][i]
+        f.lights["model"][i] = m.astype(np.float32).ravel()
+    return f
+
+
+def _worker(rank, world, port, out_path, with_mesh=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        f = _frame()
+        f = _local_light_frame() if with_mesh else _frame()
         plan = StripPlan.make(rank, world, H)
         r = StripRenderer(plan, W, backend=OracleBackend())
-        r.render(f.rows(plan.row0, plan.row0 + plan.rows))
+        r.render(f.rows(plan.row0, plan.row0 + plan.rows), synth.make_sphere_mesh() if with_mesh else None)
         parts = r.gather(0)
         if rank == 0:
             np.save(out_path, torch.cat(parts, 0).numpy())
@@ -85,6 +105,22 @@ def test_strips_reassemble_to_the_single_device_image(world, tmp_path, oracle):
     got = np.load(out_path)
     assert got.shape == want.shape
     assert np.array_equal(got, want)
+
+
+def test_strips_with_light_volume_coverage(tmp_path, oracle):
+    """Each rank rasterises the light volumes for its own rows (placed in the frame by row0): the
+    assembled image is the single-device image under the whole-frame masks."""
+    f = _local_light_frame()
+    verts, tris = synth.make_sphere_mesh()
+    masks = oracle.light_coverage(f.scene, f.lights, verts, tris, W, H)
+    frac = oracle.coverage_to_image(masks, W, H).mean()
+    assert 0.02 < frac < 0.95, frac
+    color, thr = oracle.shade(f, coverage=masks)
+    b2 = oracle.bloom_blur(oracle.bloom_blur(thr, True, oracle.WRAP_REPEAT), False, oracle.WRAP_CLAMP)
+    want = oracle.postprocess(color, b2)
+    out_path = str(tmp_path / "ldr.npy")
+    mp.spawn(_worker, args=(3, _free_port(), out_path, True), nprocs=3, join=True)
+    assert np.array_equal(np.load(out_path), want)
 
 
 def test_strip_plan_covers_the_frame():

@@ -176,5 +176,32 @@ def main(spv_dir):
     print("done", time.time() - t0, "s")
 
 
+def light_vert_vectors(spv_dir):
+    """gl_Position of light.vert (the light-volume draw's vertex shader) for a few vertices and lights."""
+    from vulkanrenderer_amd import synth
+    sh = Shader(os.path.join(spv_dir, "light.vert.spv"))
+    rng = np.random.default_rng(12)
+    scene = synth.default_scene_info()
+    lights = synth.make_lights(rng, 3)
+    verts = rng.uniform(-1, 1, (24, 3)).astype(np.float32)
+    verts /= np.linalg.norm(verts, axis=1, keepdims=True).astype(np.float32)
+    # the C# matrices are row-major bytes read column-major by GLSL: GLSL column c = C# row c
+    cols = lambda m: [np.asarray(r, dtype=np.float32) for r in np.asarray(m, dtype=np.float32).reshape(4, 4)]
+    block = [cols(scene["camera_view"]), cols(scene["camera_projection"]), scene["camera_position"]]
+    pos = np.zeros((len(lights), len(verts), 4), np.float32)
+    for li in range(len(lights)):
+        push = [cols(lights["model"][li]), lights["position"][li], lights["color"][li]]
+        for vi in range(len(verts)):
+            pos[li, vi] = sh.run({0: verts[vi]}, {(0, 0): block, "push": push})["out"]["builtin"][0]
+    np.savez_compressed(os.path.join(OUT, "light_vert.npz"), scene=scene, lights=lights, verts=verts, gl_position=pos)
+    print("light.vert vectors written")
+
+
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "/root/reference/compiled_shaders")
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    spv = args[0] if args else "/root/reference/compiled_shaders"
+    if "--only-light-vert" in sys.argv:
+        light_vert_vectors(spv)
+    else:
+        main(spv)
+        light_vert_vectors(spv)

@@ -315,7 +315,9 @@ class Shader:
             elif sc == 3:    # Output
                 cell = [self._default(pt[2])]
                 self.globals[gid] = Pointer(cell)
-                outputs[dec[30][0]] = cell
+                outputs[dec[30][0] if 30 in dec else "builtin"] = cell  # no Location: the gl_PerVertex block
+            elif sc == 2:    # Uniform (a uniform block: list of members, matrices as lists of columns)
+                self.globals[gid] = Pointer([list(resources[(dec[34][0], dec[33][0])])])
             elif sc == 0:    # UniformConstant (samplers)
                 self.globals[gid] = Pointer([resources[(dec[34][0], dec[33][0])]])
             elif sc == 9:    # PushConstant
@@ -413,6 +415,15 @@ class Shader:
                     for c in range(1, len(cols)):
                         acc = _f(acc + _f(cols[c] * v[c]))
                     env[a[1]] = _f(acc)
+                elif op == 146:  # MatrixTimesMatrix: column j of the result = left * (column j of right)
+                    left, right = val(a[2]), val(a[3])
+                    res = []
+                    for rc in right:
+                        acc = left[0] * rc[0]
+                        for c in range(1, len(left)):
+                            acc = _f(acc + _f(left[c] * rc[c]))
+                        res.append(_f(acc))
+                    env[a[1]] = res
                 elif op == 148:  # Dot
                     x, y = val(a[2]), val(a[3])
                     acc = F(x[0] * y[0])

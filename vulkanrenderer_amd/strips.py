@@ -66,6 +66,12 @@ class HipBackend:
     def shade(self, frame, color, thr):
         self.P.shade(frame, color, thr)
 
+    def with_coverage(self, frame, volume_mesh, frame_rows, row0):
+        """The strip's frame with light-volume masks attached; `volume_mesh` = (verts, triangles) device tensors."""
+        import dataclasses
+        verts, tris = volume_mesh
+        return dataclasses.replace(frame, coverage=self.P.light_coverage(frame, verts, tris, frame_rows, row0))
+
     def bloom_h(self, thr, bloom1, rows):
         # writes rows [HALO, HALO + rows) of the halo-padded pass-1 image
         self.P.bloom_blur(thr, bloom1[HALO:HALO + rows], True, _lib.WRAP_REPEAT, rows=rows)
@@ -107,11 +113,15 @@ class StripRenderer:
         for req in self.start_halo_exchange():
             req.wait()
 
-    def render(self, frame) -> torch.Tensor:
+    def render(self, frame, volume_mesh=None) -> torch.Tensor:
         """composition -> bloom 1 -> halo exchange overlapped with the interior rows of bloom 2 +
-        post-process -> the rows next to a neighbour; returns the RGBA8 strip."""
+        post-process -> the rows next to a neighbour; returns the RGBA8 strip.  With `volume_mesh`
+        each light's draw is limited to the pixels its volume covers; the strip's place in the
+        frame (plan.row0 of plan.total_rows) enters the projection, nothing is exchanged for it."""
         p, r = self.plan, self.plan.rows
         be = self.backend
+        if volume_mesh is not None:
+            frame = be.with_coverage(frame, volume_mesh, p.total_rows, p.row0)
         be.shade(frame, self.color, self.threshold)
         be.bloom_h(self.threshold, self.bloom1, r)
         # frame edges clamp (CLAMP_TO_EDGE); interior strip edges read the neighbours' rows
