@@ -232,7 +232,8 @@ def main() -> None:
 
     f, dev_frame = build_inputs(rank, device, HEIGHT, args.lights, args.cube_res, args.dir_res)
     plan = StripPlan.make(rank, world, HEIGHT * world)
-    renderer = StripRenderer(plan, WIDTH, device=device)
+    # two frames in flight, like the reference (VulkanRenderer.cs:60): the gather of frame k overlaps frame k+1
+    renderer = StripRenderer(plan, WIDTH, device=device, frames_in_flight=2 if world > 1 else 1)
 
     def step():
         renderer.render(dev_frame)

@@ -94,3 +94,44 @@ def test_hip_strips_with_light_volume_coverage(gpu, oracle, tmp_path):
     got = np.load(out_path)
     assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
     assert not np.array_equal(want, oracle.frame_chain(f)["ldr"])  # the masks matter for this frame
+
+
+def _pipelined_worker(rank, world, port, out_path):
+    import torch
+    import torch.distributed as dist
+    from vulkanrenderer_amd import passes as P
+    from vulkanrenderer_amd.strips import StripPlan, StripRenderer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        plan = StripPlan.make(rank, world, H)
+        r = StripRenderer(plan, W, device=dev, frames_in_flight=2)
+        assert r._side is not None
+        held = []
+        for seed in (91, 92, 93, 94):  # four frames through two output strips, gathers on the side stream
+            f = synth.make_frame(seed, W, H, LIGHTS, 32, 128, irr_res=8, pref_res=16, lut_res=32)
+            r.render(P.DeviceFrame.upload(f.rows(plan.row0, plan.row0 + plan.rows), dev))
+            parts = r.gather(0)
+            if rank == 0:
+                torch.cuda.synchronize()  # the receive buffers are reused by the next gather
+                held.append(torch.cat([p.cpu() for p in parts], 0).numpy())
+        torch.cuda.synchronize()
+        if rank == 0:
+            np.save(out_path, np.stack(held))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_hip_strips_with_two_frames_in_flight(gpu, tmp_path):
+    import torch.multiprocessing as mp
+    from vulkanrenderer_amd import passes as P
+    from vulkanrenderer_amd.strips import StripPlan, StripRenderer
+    out_path = str(tmp_path / "frames.npy")
+    mp.spawn(_pipelined_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    got = np.load(out_path)
+    whole = StripRenderer(StripPlan.make(0, 1, H), W, device=gpu)
+    for k, seed in enumerate((91, 92, 93, 94)):
+        f = synth.make_frame(seed, W, H, LIGHTS, 32, 128, irr_res=8, pref_res=16, lut_res=32)
+        want = whole.render(P.DeviceFrame.upload(f, gpu)).cpu().numpy()
+        assert np.array_equal(got[k], want), seed

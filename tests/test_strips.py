@@ -123,6 +123,35 @@ def test_strips_with_light_volume_coverage(tmp_path, oracle):
     assert np.array_equal(np.load(out_path), want)
 
 
+def _pipelined_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        plan = StripPlan.make(rank, world, H)
+        r = StripRenderer(plan, W, backend=OracleBackend(), frames_in_flight=2)
+        frames = []
+        for seed in (77, 78, 79):  # three different frames through two output buffers
+            f = synth.make_frame(seed, W, H, LIGHTS, 16, 64, irr_res=4, pref_res=8, lut_res=16)
+            r.render(f.rows(plan.row0, plan.row0 + plan.rows))
+            parts = r.gather(0)
+            if rank == 0:
+                frames.append(torch.cat(parts, 0).numpy().copy())
+        if rank == 0:
+            np.save(out_path, np.stack(frames))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_frames_in_flight_keep_their_images(tmp_path, oracle):
+    """Two output strips used in turn: every gathered frame is still its own image."""
+    out_path = str(tmp_path / "frames.npy")
+    mp.spawn(_pipelined_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    got = np.load(out_path)
+    for k, seed in enumerate((77, 78, 79)):
+        f = synth.make_frame(seed, W, H, LIGHTS, 16, 64, irr_res=4, pref_res=8, lut_res=16)
+        assert np.array_equal(got[k], oracle.frame_chain(f)["ldr"]), seed
+
+
 def test_strip_plan_covers_the_frame():
     for total, world in [(2160, 8), (37, 3), (16, 4), (17, 4)]:
         plans = [StripPlan.make(r, world, total) for r in range(world)]

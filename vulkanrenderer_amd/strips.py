@@ -84,14 +84,21 @@ class HipBackend:
 class StripRenderer:
     """Runs the per-frame chain on this rank's strip.  `backend` defaults to the HIP kernels."""
 
-    def __init__(self, plan: StripPlan, width: int, device=None, backend=None, group=None):
+    def __init__(self, plan: StripPlan, width: int, device=None, backend=None, group=None, frames_in_flight: int = 1):
+        """`frames_in_flight` > 1 (the reference keeps 2, VulkanRenderer.cs:60): that many RGBA8 output
+        strips, so that gather() of one frame can run on a side stream while the next frame is shaded."""
         self.plan, self.width, self.group = plan, width, group
         self.backend = backend if backend is not None else HipBackend(device)
         r = plan.rows
         self.color = self.backend.empty((r, width, 4), torch.float16)
         self.threshold = self.backend.empty((r, width, 4), torch.float16)
         self.bloom1 = self.backend.empty((r + 2 * HALO, width, 4), torch.float16)
-        self.ldr = self.backend.empty((r, width, 4), torch.uint8)
+        self._ring = [self.backend.empty((r, width, 4), torch.uint8) for _ in range(max(frames_in_flight, 1))]
+        self._slot = 0
+        self.ldr = self._ring[0]
+        on_gpu = self.ldr.is_cuda
+        self._side = torch.cuda.Stream(device=self.ldr.device) if on_gpu and len(self._ring) > 1 and plan.world > 1 else None
+        self._slot_free = [None] * len(self._ring)  # per output strip: event "its last gather has finished"
         self._gathered = None  # receive buffers of gather(), allocated on first use
 
     def start_halo_exchange(self) -> list:
@@ -120,6 +127,10 @@ class StripRenderer:
         frame (plan.row0 of plan.total_rows) enters the projection, nothing is exchanged for it."""
         p, r = self.plan, self.plan.rows
         be = self.backend
+        self.ldr = self._ring[self._slot]
+        if self._slot_free[self._slot] is not None:  # this output strip may still be on its way to rank 0
+            torch.cuda.current_stream().wait_event(self._slot_free[self._slot])
+            self._slot_free[self._slot] = None
         if volume_mesh is not None:
             frame = be.with_coverage(frame, volume_mesh, p.total_rows, p.row0)
         be.shade(frame, self.color, self.threshold)
@@ -142,20 +153,38 @@ class StripRenderer:
         return self.ldr
 
     def gather(self, dst: int = 0):
-        """Collects the RGBA8 strips on rank `dst` (list of tensors there, None elsewhere)."""
+        """Collects the RGBA8 strips of the frame just rendered on rank `dst` (list of tensors there, None
+        elsewhere).  With several frames in flight on a GPU the transfer runs on a side stream and the
+        next render() goes on at once; the returned tensors are complete once that stream (or the
+        device) is synchronised."""
+        ldr = self.ldr
+        slot, self._slot = self._slot, (self._slot + 1) % len(self._ring)
+        if self.plan.world == 1:
+            return [ldr]
+        if self._side is None:
+            return self._gather_now(ldr, dst)
+        rendered = torch.cuda.Event()
+        rendered.record()
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(rendered)
+            parts = self._gather_now(ldr, dst)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        self._slot_free[slot] = done
+        return parts
+
+    def _gather_now(self, ldr, dst: int):
         p = self.plan
-        if p.world == 1:
-            return [self.ldr]
         if p.rank == dst:
             if self._gathered is None:
                 self._gathered = [self.backend.empty((StripPlan.make(k, p.world, p.total_rows).rows, self.width, 4), torch.uint8)
                                   for k in range(p.world)]
             parts = list(self._gathered)
             ops = [dist.P2POp(dist.irecv, parts[k], k, self.group) for k in range(p.world) if k != dst]
-            parts[dst] = self.ldr
+            parts[dst] = ldr
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
             return parts
-        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, self.ldr, dst, self.group)]):
+        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, ldr, dst, self.group)]):
             req.wait()
         return None
