@@ -1,6 +1,6 @@
 """Benchmark of the shading path: Mpixels/s for deferred PBR shading + bloom + ACES at 4K with 64
-shadowed point lights (BASELINE.json's metric, config "3840x2160, 64 point lights with 1024^2 cube
-shadow maps + 4K directional PCF shadow"), plus the IBL precompute time.
+shadowed point lights (the headline configuration: 3840x2160, 64 point lights with 1024^2 cube shadow
+maps + a 4096^2 directional PCF shadow map), plus the IBL precompute time.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -195,17 +195,22 @@ def cpu_baseline(f, gpu_color, gpu_thr, sample_rows: int) -> dict:
 
 
 def main() -> None:
+    global WIDTH, HEIGHT
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=WIDTH, help="strip width per GPU (default: the headline 3840)")
+    ap.add_argument("--height", type=int, default=HEIGHT, help="strip rows per GPU (default: the headline 2160)")
     ap.add_argument("--lights", type=int, default=LIGHTS)
     ap.add_argument("--cube-res", type=int, default=CUBE_RES)
     ap.add_argument("--dir-res", type=int, default=DIR_RES)
-    ap.add_argument("--cpu-rows", type=int, default=HEIGHT, help="rows of the frame the CPU baseline shades (0 = skip)")
+    ap.add_argument("--cpu-rows", type=int, default=None, help="rows of the frame the CPU baseline shades (default: all; 0 = skip)")
     ap.add_argument("--no-ibl", action="store_true", help="skip the IBL precompute timing")
     ap.add_argument("--no-coverage", action="store_true", help="skip the light-volume coverage timing")
     args = ap.parse_args()
+    WIDTH, HEIGHT = args.width, args.height
+    args.cpu_rows = HEIGHT if args.cpu_rows is None else min(args.cpu_rows, HEIGHT)
 
     import torch
     import torch.distributed as dist

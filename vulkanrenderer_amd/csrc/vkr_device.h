@@ -102,17 +102,6 @@ VKR_DEV void cube_st(f3 r, int &face, float &s, float &t)
     t = fma_(tc * ima, 0.5f, 0.5f);
 }
 
-// NEAREST lookup in a D32F cube (shadowSampler on a cube view)
-VKR_DEV float texcube_depth_nearest(const float *cube, int res, f3 r)
-{
-    int face; float s, t;
-    cube_st(r, face, s, t);
-    int i = (int)__builtin_floorf(s * (float)res), j = (int)__builtin_floorf(t * (float)res);
-    i = min(max(i, 0), res - 1);
-    j = min(max(j, 0), res - 1);
-    return cube[((size_t)face * res + j) * res + i];
-}
-
 // Texel one step over a face edge -> the touching texel of the adjacent face (seamless cube
 // filtering), on the integer lattice a = 2i+1-n.  Returns false at a cube corner.
 VKR_DEV bool cube_fold(int n, int f, int i, int j, int &of, int &oi, int &oj)
