@@ -144,6 +144,40 @@ typedef struct VkrCoverageArgs {
 } VkrCoverageArgs;
 VKR_EXPORT int32_t vkr_light_coverage(const VkrCoverageArgs *args, void *stream);
 
+/* Shadow-map generation: the passes that produce the depth images vkr_shade reads.
+ * One draw of the reference's solidModelDrawCalls list (VulkanRenderer.cs:357-366): a mesh and its model matrix. */
+typedef struct VkrMeshDraw {
+    const float *positions;    /* device memory, 3 floats per vertex */
+    int32_t n_verts;
+    const uint32_t *indices;   /* device memory, 3 per triangle, counter-clockwise seen from outside */
+    int32_t n_tris;
+    float model[16];           /* DrawCall.ModelMatrix, row-major bytes as the reference pushes them */
+} VkrMeshDraw;
+
+/* Replaces the point-shadow render passes (VulkanRenderer.cs:325-376; point_shadow.vert/.geom/.frag):
+ * for every light a depth cube holding length(fragment - light) / far_plane of the nearest surface the
+ * FRONT-culled, LESS-tested draws leave, cleared to 1.0.  Shadow matrices as VulkanRenderer.cs:327-339
+ * (90 degree perspective, near plane 1).  `draws` is a host array; its meshes and `lights` are device memory. */
+typedef struct VkrPointShadowArgs {
+    const VkrMeshDraw *draws; int32_t n_draws;
+    const VkrLightInfo *lights; int32_t n_lights;   /* positions are read */
+    int32_t res;                /* face size (PointShadowMapResolution, 256 in the reference) */
+    float far_plane;            /* 25 in the reference (VulkanRenderer.cs:331) */
+    int32_t layout;             /* VKR_CUBE_LAYOUT_* of `out` */
+    float *out;                 /* device memory, n_lights * 6 * res^2 */
+} VkrPointShadowArgs;
+VKR_EXPORT int32_t vkr_point_shadow_maps(const VkrPointShadowArgs *args, void *stream);
+
+/* Replaces the directional depth pass (VulkanRenderer.cs:406-428; depth.vert): clip = lightSpaceMatrix * model * pos,
+ * the same raster state, the fixed-function depth z/w, row-major res^2 D32F cleared to 1.0. */
+typedef struct VkrDirShadowArgs {
+    const VkrMeshDraw *draws; int32_t n_draws;
+    float light_space[16];      /* SceneInfo.lightSpaceMatrix */
+    int32_t res;
+    float *out;
+} VkrDirShadowArgs;
+VKR_EXPORT int32_t vkr_dir_shadow_map(const VkrDirShadowArgs *args, void *stream);
+
 /* Re-lays `n_faces` D32F faces of `res`^2 texels from VKR_CUBE_LAYOUT_LINEAR to
  * VKR_CUBE_LAYOUT_TILED_8X4 (res % 8 == 0; src and dst must not overlap).  No counterpart in the
  * reference, whose depth images are written tiled by the rasteriser. */

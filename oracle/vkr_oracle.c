@@ -702,6 +702,197 @@ ORC_API void orc_light_clip_vertex(const orc_scene_info *scene, const orc_light_
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* Shadow-map generation.  Point lights: VulkanRenderer.cs:325-376 draws every solid model into the
+ * six faces of a depth cube per light through point_shadow.vert (world = model * pos),
+ * point_shadow.geom (clip = shadowMatrices[face] * world, the world position passed on) and
+ * point_shadow.frag (gl_FragDepth = length(world - lightPos) / farPlane), with FRONT faces culled,
+ * CCW front, depth test LESS on a cube cleared to 1.0 (GraphicsPipeline.cs:262-264).
+ * Directional light: VulkanRenderer.cs:406-428 through depth.vert
+ * (clip = lightSpaceMatrix * model * pos), the same raster state, the fixed-function depth.
+ * Which texels a triangle covers and how the world position is interpolated belong to the
+ * rasteriser; they are restated as in orc_light_coverage (texel centre inside the projected
+ * back-facing triangle, homogeneous binary64 edge functions, depth clip 0 <= z <= w), the
+ * interpolation being the perspective-correct one: attribute = sum(Ei * ai) / sum(Ei).
+ * The result per texel is a minimum over the triangles covering it, so it does not depend on
+ * the order triangles are drawn in.
+ *
+ * Shadow matrices (VulkanRenderer.cs:327-339): CreateLookAt(pos, pos + dir, up) *
+ * CreatePerspectiveFieldOfView(pi/2, 1, 1, farPlane) in binary32.  The look-at axes are exact
+ * signed unit vectors; 1/tan(pi/4) is taken as exactly 1. */
+
+typedef struct {
+    const float *positions; int32_t n_verts;   /* 3 floats per vertex */
+    const uint32_t *indices; int32_t n_tris;   /* 3 per triangle */
+    float model[16];                           /* DrawCall.ModelMatrix, row-major, row-vector convention */
+} orc_mesh_draw;
+
+typedef struct {
+    const orc_mesh_draw *draws; int32_t n_draws;
+    const orc_light_info *lights; int32_t n_lights;   /* positions are read */
+    int32_t res; float far_plane;
+    float *out;                                        /* n_lights * 6 * res * res, row-major faces */
+} orc_point_shadow_args;
+
+typedef struct {
+    const orc_mesh_draw *draws; int32_t n_draws;
+    const float *light_space;                          /* SceneInfo.lightSpaceMatrix */
+    int32_t res;
+    float *out;                                        /* res * res */
+} orc_dir_shadow_args;
+
+static const float SHADOW_DIR[6][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+static const float SHADOW_UP[6][3] = {{0, -1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}, {0, -1, 0}, {0, -1, 0}};
+
+/* CreateLookAt(eye, eye + dir, up) * CreatePerspectiveFieldOfView(pi/2, 1, near = 1, far) */
+static void shadow_face_matrix(const float *eye, int face, float far_plane, float *out16)
+{
+    const float *d = SHADOW_DIR[face], *u = SHADOW_UP[face];
+    const float z[3] = {-d[0], -d[1], -d[2]};                              /* normalize(eye - target) */
+    const float x[3] = {u[1] * z[2] - u[2] * z[1], u[2] * z[0] - u[0] * z[2], u[0] * z[1] - u[1] * z[0]}; /* cross(up, z), already unit */
+    const float y[3] = {z[1] * x[2] - z[2] * x[1], z[2] * x[0] - z[0] * x[2], z[0] * x[1] - z[1] * x[0]}; /* cross(z, x) */
+    float view[16] = {x[0], y[0], z[0], 0, x[1], y[1], z[1], 0, x[2], y[2], z[2], 0, 0, 0, 0, 1};
+    view[12] = -fmaf(x[2], eye[2], fmaf(x[1], eye[1], x[0] * eye[0]));
+    view[13] = -fmaf(y[2], eye[2], fmaf(y[1], eye[1], y[0] * eye[0]));
+    view[14] = -fmaf(z[2], eye[2], fmaf(z[1], eye[1], z[0] * eye[0]));
+    const float range = far_plane * rcpf_(1.0f - far_plane);              /* far / (near - far), near = 1 */
+    const float proj[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, range, -1, 0, 0, range, 0};
+    mat4_mul(view, proj, out16);
+}
+
+/* GLSL mat4 * vec4 on row-major bytes: out[j] = sum_i v[i] * m[4i + j] */
+static void mat4_vec4(const float *m, const float *v, float *out4)
+{
+    for (int j = 0; j < 4; j++)
+        out4[j] = fmaf(v[3], m[12 + j], fmaf(v[2], m[8 + j], fmaf(v[1], m[4 + j], v[0] * m[j])));
+}
+
+/* Conservative texel bounding box of the part of a clip-space triangle with z >= 0 (and w > 0).
+ * Returns 0 when nothing can be covered. */
+static int shadow_bbox(const float (*c)[4], int res, int *bx0, int *by0, int *bx1, int *by1)
+{
+    double poly[8][4];
+    int n = 0;
+    for (int i = 0; i < 3; i++) {
+        const float *a = c[i], *b = c[(i + 1) % 3];
+        const int ain = a[2] >= 0.0f && a[3] > 0.0f, bin = b[2] >= 0.0f && b[3] > 0.0f;
+        if (ain) { for (int k = 0; k < 4; k++) poly[n][k] = a[k]; n++; }
+        if (ain != bin) {
+            /* crossing of z = 0 (or of w = 0 when z stays positive): take both candidates' safer one */
+            double ta = (double)a[2], tb = (double)b[2];
+            double t = (ta != tb) ? ta / (ta - tb) : 0.5;
+            if (!(t >= 0.0 && t <= 1.0)) { double wa = a[3], wb = b[3]; t = (wa != wb) ? wa / (wa - wb) : 0.5; }
+            for (int k = 0; k < 4; k++) poly[n][k] = (double)a[k] + t * ((double)b[k] - (double)a[k]);
+            n++;
+        }
+    }
+    if (n == 0) return 0;
+    double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
+    for (int i = 0; i < n; i++) {
+        const double w = poly[i][3];
+        if (!(w > 1e-12)) { xmin = ymin = -1e300; xmax = ymax = 1e300; break; }  /* cannot bound: whole face */
+        const double x = poly[i][0] / w, y = poly[i][1] / w;
+        if (x < xmin) xmin = x;
+        if (x > xmax) xmax = x;
+        if (y < ymin) ymin = y;
+        if (y > ymax) ymax = y;
+    }
+    const double half = 0.5 * (double)res;
+    double fx0 = floor((xmin + 1.0) * half - 0.5) - 1.0, fx1 = ceil((xmax + 1.0) * half - 0.5) + 1.0;
+    double fy0 = floor((ymin + 1.0) * half - 0.5) - 1.0, fy1 = ceil((ymax + 1.0) * half - 0.5) + 1.0;
+    if (!(fx0 > 0.0)) fx0 = 0.0;
+    if (!(fy0 > 0.0)) fy0 = 0.0;
+    if (!(fx1 < (double)(res - 1))) fx1 = (double)(res - 1);
+    if (!(fy1 < (double)(res - 1))) fy1 = (double)(res - 1);
+    if (fx0 > fx1 || fy0 > fy1) return 0;
+    *bx0 = (int)fx0; *by0 = (int)fy0; *bx1 = (int)fx1; *by1 = (int)fy1;
+    return 1;
+}
+
+/* Rasterises one triangle into one res x res depth image.  clip: the three clip-space corners;
+ * world: their world positions (point lights) or NULL (directional: fixed-function depth). */
+static void shadow_raster(const float (*clip)[4], const float (*world)[4], const float *light_pos, float inv_far, int res, float *img)
+{
+    cov_tri t;
+    if (!cov_setup(clip[0], clip[1], clip[2], &t)) return;
+    int bx0, by0, bx1, by1;
+    if (!shadow_bbox(clip, res, &bx0, &by0, &bx1, &by1)) return;
+    const double sc = 2.0 / (double)res;
+    for (int j = by0; j <= by1; j++) {
+        const double yn = fma((double)j + 0.5, sc, -1.0);
+        for (int i = bx0; i <= bx1; i++) {
+            const double xn = fma((double)i + 0.5, sc, -1.0);
+            const double e0 = cov_edge(&t, 0, xn, yn), e1 = cov_edge(&t, 1, xn, yn), e2 = cov_edge(&t, 2, xn, yn);
+            const double s = (e0 + e1) + e2;
+            if (!(e0 >= 0.0 && e1 >= 0.0 && e2 >= 0.0 && s > 0.0)) continue;
+            const double zs = fma(e2, t.z[2], fma(e1, t.z[1], e0 * t.z[0]));
+            if (!(zs >= 0.0 && zs <= t.D)) continue;
+            float depth;
+            if (world) { /* point_shadow.frag:11-16 on the interpolated world position */
+                float p[3];
+                for (int k = 0; k < 3; k++)
+                    p[k] = (float)(fma(e2, (double)world[2][k], fma(e1, (double)world[1][k], e0 * (double)world[0][k])) / s);
+                v3 d = v3_(p[0] - light_pos[0], p[1] - light_pos[1], p[2] - light_pos[2]);
+                depth = sqrtf(dot3(d, d)) * inv_far;
+            } else {
+                depth = (float)(zs / t.D) + 0.0f; /* z / w of the fixed-function pipeline (-0 becomes +0) */
+            }
+            float *o = img + (size_t)j * res + i;
+            if (depth < *o) *o = depth; /* CompareOp.Less, depth writes on */
+        }
+    }
+}
+
+ORC_API void orc_point_shadow_maps(const orc_point_shadow_args *a)
+{
+    const size_t face_texels = (size_t)a->res * a->res;
+    const float inv_far = rcpf_(a->far_plane);
+    for (size_t i = 0; i < (size_t)a->n_lights * 6 * face_texels; i++) a->out[i] = 1.0f; /* clear value */
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int lf = 0; lf < a->n_lights * 6; lf++) {
+        const int li = lf / 6, face = lf % 6;
+        const float *lp = a->lights[li].position;
+        float m[16];
+        shadow_face_matrix(lp, face, a->far_plane, m);
+        float *img = a->out + (size_t)lf * face_texels;
+        for (int d = 0; d < a->n_draws; d++) {
+            const orc_mesh_draw *dr = a->draws + d;
+            for (int t = 0; t < dr->n_tris; t++) {
+                float world[3][4], clip[3][4];
+                for (int k = 0; k < 3; k++) {
+                    const float *v = dr->positions + 3 * (size_t)dr->indices[3 * t + k];
+                    const float v4[4] = {v[0], v[1], v[2], 1.0f};
+                    mat4_vec4(dr->model, v4, world[k]);   /* point_shadow.vert:12 */
+                    mat4_vec4(m, world[k], clip[k]);      /* point_shadow.geom:20 */
+                }
+                shadow_raster(clip, world, lp, inv_far, a->res, img);
+            }
+        }
+    }
+}
+
+ORC_API void orc_dir_shadow_map(const orc_dir_shadow_args *a)
+{
+    const size_t texels = (size_t)a->res * a->res;
+    for (size_t i = 0; i < texels; i++) a->out[i] = 1.0f;
+    for (int d = 0; d < a->n_draws; d++) {
+        const orc_mesh_draw *dr = a->draws + d;
+        float mvp[16];
+        mat4_mul(dr->model, a->light_space, mvp);         /* depth.vert:13, associated as lightSpace * model */
+        for (int t = 0; t < dr->n_tris; t++) {
+            float clip[3][4];
+            for (int k = 0; k < 3; k++) {
+                const float *v = dr->positions + 3 * (size_t)dr->indices[3 * t + k];
+                const float v4[4] = {v[0], v[1], v[2], 1.0f};
+                mat4_vec4(mvp, v4, clip[k]);
+            }
+            shadow_raster(clip, NULL, NULL, 0.0f, a->res, a->out);
+        }
+    }
+}
+
+ORC_API void orc_shadow_face_matrix(const float *eye, int face, float far_plane, float *out16) { shadow_face_matrix(eye, face, far_plane, out16); }
+
+/* ------------------------------------------------------------------------------------------ */
 /* bloom_blur.frag:14-33.  wrap = REPEAT for pass 1 (reads the thresholded target through
  * textureSampler), CLAMP for pass 2 (bloomSampler): VulkanRenderer.cs:231-235.
  * true_bilinear = 0: fetch the texel whose centre the coordinate names;

@@ -39,6 +39,20 @@ class CoverageArgs(C.Structure):
                 ("masks", C.c_void_p)]
 
 
+class MeshDraw(C.Structure):
+    _fields_ = [("positions", C.c_void_p), ("n_verts", C.c_int32), ("indices", C.c_void_p), ("n_tris", C.c_int32),
+                ("model", C.c_float * 16)]
+
+
+class PointShadowArgs(C.Structure):
+    _fields_ = [("draws", C.c_void_p), ("n_draws", C.c_int32), ("lights", C.c_void_p), ("n_lights", C.c_int32),
+                ("res", C.c_int32), ("far_plane", C.c_float), ("out", C.c_void_p)]
+
+
+class DirShadowArgs(C.Structure):
+    _fields_ = [("draws", C.c_void_p), ("n_draws", C.c_int32), ("light_space", C.c_void_p), ("res", C.c_int32), ("out", C.c_void_p)]
+
+
 def build() -> None:
     subprocess.run(["make", "-C", ORACLE_DIR, "-s"], check=True)
 
@@ -120,6 +134,51 @@ def light_clip_vertex(scene: np.ndarray, light: np.ndarray, v) -> np.ndarray:
     out = np.empty(4, dtype=np.float32)
     load().orc_light_clip_vertex(_p(scene), _p(light), _p(v), _p(out))
     return out
+
+
+def _mesh_draws(draws):
+    """draws: list of (positions [n,3] f32, triangles [m,3] u32, model [4,4] or 16 floats); returns (array, keepalive)."""
+    arr = (MeshDraw * len(draws))()
+    keep = []
+    for k, (pos, tri, model) in enumerate(draws):
+        pos = np.ascontiguousarray(pos, dtype=np.float32)
+        tri = np.ascontiguousarray(tri, dtype=np.uint32)
+        keep += [pos, tri]
+        arr[k].positions, arr[k].n_verts = pos.ctypes.data, len(pos)
+        arr[k].indices, arr[k].n_tris = tri.ctypes.data, len(tri)
+        arr[k].model[:] = [float(v) for v in np.asarray(model, dtype=np.float32).ravel()]
+    return arr, keep
+
+
+def point_shadow_maps(draws, lights: np.ndarray, res: int, far_plane: float = 25.0) -> np.ndarray:
+    """Depth cubes float32 [n_lights, 6, res, res] of the point-shadow pass (VulkanRenderer.cs:325-376)."""
+    arr, keep = _mesh_draws(draws)
+    lights = np.ascontiguousarray(lights)
+    out = np.empty((len(lights), 6, res, res), dtype=np.float32)
+    a = PointShadowArgs()
+    a.draws, a.n_draws = C.addressof(arr), len(draws)
+    a.lights, a.n_lights = (_p(lights) if len(lights) else C.c_void_p(0)), len(lights)
+    a.res, a.far_plane, a.out = res, far_plane, _p(out)
+    load().orc_point_shadow_maps(C.byref(a))
+    return out
+
+
+def dir_shadow_map(draws, light_space: np.ndarray, res: int) -> np.ndarray:
+    """Depth map float32 [res, res] of the directional shadow pass (VulkanRenderer.cs:406-428)."""
+    arr, keep = _mesh_draws(draws)
+    ls = np.ascontiguousarray(light_space, dtype=np.float32).ravel()
+    out = np.empty((res, res), dtype=np.float32)
+    a = DirShadowArgs()
+    a.draws, a.n_draws, a.light_space, a.res, a.out = C.addressof(arr), len(draws), _p(ls), res, _p(out)
+    load().orc_dir_shadow_map(C.byref(a))
+    return out
+
+
+def shadow_face_matrix(eye, face: int, far_plane: float = 25.0) -> np.ndarray:
+    eye = np.ascontiguousarray(eye, dtype=np.float32)
+    out = np.empty(16, dtype=np.float32)
+    load().orc_shadow_face_matrix(_p(eye), face, C.c_float(far_plane), _p(out))
+    return out.reshape(4, 4)
 
 
 def shade(f, background: np.ndarray | None = None, rows: tuple[int, int] | None = None, coverage: np.ndarray | None = None):

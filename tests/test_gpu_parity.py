@@ -520,3 +520,79 @@ def test_renderer_with_light_volume_mesh(gpu, oracle):
         want_c, want_t = oracle.shade(f, coverage=masks)
         assert_bits_equal(r.Read(_lib.TARGET_COLOR, 0), want_c, "colour")
         assert_bits_equal(r.Read(_lib.TARGET_THRESHOLD, 0), want_t, "threshold")
+
+
+def _device_draws(draws, gpu):
+    torch = _torch()
+    return [(torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(gpu),
+             torch.from_numpy(np.ascontiguousarray(t).astype(np.int32)).to(gpu), m) for v, t, m in draws]
+
+
+@pytest.mark.parametrize("res,tiled", [(64, False), (64, True), (90, False)])
+def test_point_shadow_maps_bit_exact(gpu, oracle, res, tiled):
+    """vkr_point_shadow_maps against the oracle: the closed height-field slab plus a moved, scaled sphere,
+    lights above, beside and inside the geometry; row-major and tiled output."""
+    torch, P = _torch(), _passes()
+    slab = synth.make_scene_mesh(24)
+    ball = synth.make_sphere_mesh(16, 8)
+    model = np.diag([0.6, 0.6, 0.6, 1.0]); model[3, :3] = (1.0, 0.9, -0.5)
+    draws = [(slab[0], slab[1], np.eye(4)), (ball[0], ball[1], model)]
+    lights = synth.make_lights(np.random.default_rng(17), 5)
+    lights["position"][0] = (0.2, 2.5, 0.1)
+    lights["position"][1] = (1.0, 0.9, -0.5)      # inside the sphere
+    lights["position"][2] = (-2.9, 0.15, 2.0)     # just above the slab near its rim
+    want = oracle.point_shadow_maps(draws, lights, res)
+    assert 0.05 < (want < 1.0).mean() < 0.95
+    dev_lights = torch.from_numpy(np.frombuffer(lights.tobytes(), dtype=np.uint8).copy()).to(gpu)
+    got, layout = P.point_shadow_maps(_device_draws(draws, gpu), dev_lights, len(lights), res, tiled=tiled)
+    got = got.cpu().numpy()
+    if tiled:
+        j, i = np.meshgrid(np.arange(res), np.arange(res), indexing="ij")
+        index = ((j >> 2) * (res >> 3) + (i >> 3)) * 32 + (j & 3) * 8 + (i & 7)
+        got = got.reshape(len(lights), 6, -1)[:, :, index.ravel()].reshape(want.shape)
+    bad = got.view(np.uint32) != want.view(np.uint32)
+    assert not bad.any(), f"{bad.sum()} of {bad.size} texels differ, first at {np.argwhere(bad)[0]}"
+
+
+def test_dir_shadow_map_bit_exact(gpu, oracle):
+    torch, P = _torch(), _passes()
+    slab = synth.make_scene_mesh(24)
+    ball = synth.make_sphere_mesh(16, 8)
+    model = np.diag([0.6, 0.6, 0.6, 1.0]); model[3, :3] = (1.0, 0.9, -0.5)
+    draws = [(slab[0], slab[1], np.eye(4)), (ball[0], ball[1], model)]
+    ls = synth.default_scene_info()["light_space_matrix"]
+    want = oracle.dir_shadow_map(draws, ls, 192)
+    assert 0.02 < (want < 1.0).mean() < 0.9
+    got = P.dir_shadow_map(_device_draws(draws, gpu), ls, 192, gpu).cpu().numpy()
+    bad = got.view(np.uint32) != want.view(np.uint32)
+    assert not bad.any(), f"{bad.sum()} of {bad.size} texels differ"
+
+
+def test_generated_shadow_maps_feed_the_shading_pass(gpu, oracle):
+    """End to end: shadow maps made by the library from the scene mesh (tiled cubes straight from the pass)
+    shade to the bits the oracle gets from its own maps."""
+    torch, P = _torch(), _passes()
+    w, h, nl = 128, 72, 3
+    slab = synth.make_scene_mesh(24)
+    draws = [(slab[0], slab[1], np.eye(4))]
+    f = synth.make_frame(81, w, h, nl, 64, 128, irr_res=8, pref_res=16, lut_res=32)
+    f.cube_shadow = oracle.point_shadow_maps(draws, f.lights, 64)
+    f.dir_shadow = oracle.dir_shadow_map(draws, f.scene["light_space_matrix"], 128)
+    want_c, want_t = oracle.shade(f)
+    d = P.DeviceFrame.upload(f, gpu)
+    ddraws = _device_draws(draws, gpu)
+    d.cube_shadow, d.cube_layout = P.point_shadow_maps(ddraws, d.lights, nl, 64)
+    assert d.cube_layout == _lib.CUBE_LAYOUT_TILED_8X4
+    d.dir_shadow = P.dir_shadow_map(ddraws, f.scene["light_space_matrix"], 128, gpu)
+    color = torch.empty((h, w, 4), dtype=torch.float16, device=gpu)
+    thr = torch.empty_like(color)
+    P.shade(d, color, thr)
+    assert_bits_equal(P.f16_bits(color), want_c, "colour under generated shadow maps")
+    assert_bits_equal(P.f16_bits(thr), want_t, "threshold under generated shadow maps")
+    lit = oracle.shade(dataclasses_replace(f))[0]
+    assert (f.cube_shadow < 1.0).any() and lit.shape == want_c.shape
+
+
+def dataclasses_replace(f):
+    import dataclasses
+    return dataclasses.replace(f)

@@ -71,6 +71,21 @@ class CoverageArgs(C.Structure):
                 ("masks", C.c_void_p)]
 
 
+class MeshDraw(C.Structure):
+    _fields_ = [("positions", C.c_void_p), ("n_verts", C.c_int32), ("indices", C.c_void_p), ("n_tris", C.c_int32),
+                ("model", C.c_float * 16)]
+
+
+class PointShadowArgs(C.Structure):
+    _fields_ = [("draws", C.POINTER(MeshDraw)), ("n_draws", C.c_int32), ("lights", C.c_void_p), ("n_lights", C.c_int32),
+                ("res", C.c_int32), ("far_plane", C.c_float), ("layout", C.c_int32), ("out", C.c_void_p)]
+
+
+class DirShadowArgs(C.Structure):
+    _fields_ = [("draws", C.POINTER(MeshDraw)), ("n_draws", C.c_int32), ("light_space", C.c_float * 16),
+                ("res", C.c_int32), ("out", C.c_void_p)]
+
+
 class BloomArgs(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("width", C.c_int32), ("rows", C.c_int32),
                 ("src_rows", C.c_int32), ("src_row_offset", C.c_int32), ("horizontal", C.c_int32),
@@ -103,6 +118,8 @@ PROTOTYPES = {
     "vkr_shade": [C.POINTER(ShadeArgs), _vp],
     "vkr_tile_depth_cubes": [_vp, _vp, C.c_int32, C.c_int32, _vp],
     "vkr_light_coverage": [C.POINTER(CoverageArgs), _vp],
+    "vkr_point_shadow_maps": [C.POINTER(PointShadowArgs), _vp],
+    "vkr_dir_shadow_map": [C.POINTER(DirShadowArgs), _vp],
     "vkr_bloom_blur": [C.POINTER(BloomArgs), _vp],
     "vkr_postprocess": [_vp, _vp, _vp, _i32, _i32, _i32, _vp],
     "vkr_bloomv_postprocess": [C.POINTER(BloomPostArgs), _vp],

@@ -1,0 +1,266 @@
+// Shadow-map generation on gfx950: the point-light depth cubes of VulkanRenderer.cs:325-376
+// (point_shadow.vert / .geom / .frag) and the directional depth map of VulkanRenderer.cs:406-428
+// (depth.vert), both with FRONT faces culled, CCW front, depth test LESS on a target cleared to
+// 1.0 (GraphicsPipeline.cs:262-264, 279-281).
+//
+// A texel belongs to a triangle when its centre lies inside the projected back-facing triangle
+// and the depth there passes the 0 <= z <= w clip -- the homogeneous binary64 rule of the
+// light-volume coverage kernel -- and the world position the fragment shader receives is the
+// perspective-correct interpolation sum(Ei * Pi) / sum(Ei).  The stored value is the minimum over
+// all covering triangles (atomicMin on the bits of a non-negative float), so the result does not
+// depend on the order of triangles, lanes or launches.
+//
+// Work layout: one lane per (light, triangle); it projects the triangle onto the six faces in
+// turn and walks the texels of its bounding box.  Output texels are addressed row-major or as
+// 8x4-texel tiles, the layout the shading kernel gathers from fastest.
+#include "vkr_device.h"
+#include "vkr_host.h"
+
+namespace vkr {
+
+struct ShadowParams {
+    const float *positions; const unsigned *indices; int n_verts, n_tris;
+    float model[16];
+    const float *lights;  // VkrLightInfo array viewed as floats (point) or null (directional)
+    float light_space[16];  // directional: lightSpaceMatrix
+    int res; float far_plane; int tiled;
+    float *out;
+};
+
+struct STri { double a[3], b[3], c[3], z[3], D; };
+
+VKR_DEV double s_edge(const STri &t, int i, double xn, double yn) { return __builtin_fma(t.a[i], xn, __builtin_fma(t.b[i], yn, t.c[i])); }
+
+// row-major 4x4 product in the row-vector convention, each element one fma chain
+VKR_DEV float mat4_mul_elem(const float *a, const float *b, int i, int j)
+{
+    return fma_(a[4 * i + 3], b[12 + j], fma_(a[4 * i + 2], b[8 + j], fma_(a[4 * i + 1], b[4 + j], a[4 * i] * b[j])));
+}
+
+// GLSL mat4 * vec4 on row-major bytes: out[j] = sum_i v[i] * m[4i + j]
+VKR_DEV void mat4_vec4(const float *m, const float (&v)[4], float (&o)[4])
+{
+#pragma unroll
+    for (int j = 0; j < 4; j++) o[j] = fma_(v[3], m[12 + j], fma_(v[2], m[8 + j], fma_(v[1], m[4 + j], v[0] * m[j])));
+}
+
+// CreateLookAt(eye, eye + dir, up) * CreatePerspectiveFieldOfView(pi/2, 1, 1, far), VulkanRenderer.cs:327-339.
+// The look-at axes are exact signed unit vectors; 1/tan(pi/4) is taken as exactly 1.
+__device__ const float SHADOW_DIR[6][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+__device__ const float SHADOW_UP[6][3] = {{0, -1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}, {0, -1, 0}, {0, -1, 0}};
+
+VKR_DEV void shadow_face_matrix_elem(const float *eye, int face, float far_plane, int idx, float *out16)
+{
+    const float *d = SHADOW_DIR[face], *u = SHADOW_UP[face];
+    const float z[3] = {-d[0], -d[1], -d[2]};
+    const float x[3] = {u[1] * z[2] - u[2] * z[1], u[2] * z[0] - u[0] * z[2], u[0] * z[1] - u[1] * z[0]};
+    const float y[3] = {z[1] * x[2] - z[2] * x[1], z[2] * x[0] - z[0] * x[2], z[0] * x[1] - z[1] * x[0]};
+    float view[16] = {x[0], y[0], z[0], 0, x[1], y[1], z[1], 0, x[2], y[2], z[2], 0, 0, 0, 0, 1};
+    view[12] = -fma_(x[2], eye[2], fma_(x[1], eye[1], x[0] * eye[0]));
+    view[13] = -fma_(y[2], eye[2], fma_(y[1], eye[1], y[0] * eye[0]));
+    view[14] = -fma_(z[2], eye[2], fma_(z[1], eye[1], z[0] * eye[0]));
+    const float range = far_plane * rcp_rn(1.0f - far_plane);
+    const float proj[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, range, -1, 0, 0, range, 0};
+    out16[idx] = mat4_mul_elem(view, proj, idx >> 2, idx & 3);
+}
+
+// Conservative texel bounding box of the part of a clip-space triangle with z >= 0 and w > 0.
+VKR_DEV bool shadow_bbox(const float (&c)[3][4], int res, int &bx0, int &by0, int &bx1, int &by1)
+{
+    double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
+    int n = 0;
+    bool unbounded = false;
+    auto add = [&](double x, double y, double w) {
+        n++;
+        if (!(w > 1e-12)) { unbounded = true; return; }
+        const double px = x / w, py = y / w;
+        xmin = px < xmin ? px : xmin; xmax = px > xmax ? px : xmax;
+        ymin = py < ymin ? py : ymin; ymax = py > ymax ? py : ymax;
+    };
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float *a = c[i], *b = c[(i + 1) % 3];
+        const bool ain = a[2] >= 0.0f && a[3] > 0.0f, bin = b[2] >= 0.0f && b[3] > 0.0f;
+        if (ain) add(a[0], a[1], a[3]);
+        if (ain != bin) {
+            const double ta = a[2], tb = b[2];
+            double t = (ta != tb) ? ta / (ta - tb) : 0.5;
+            if (!(t >= 0.0 && t <= 1.0)) { const double wa = a[3], wb = b[3]; t = (wa != wb) ? wa / (wa - wb) : 0.5; }
+            add((double)a[0] + t * ((double)b[0] - (double)a[0]), (double)a[1] + t * ((double)b[1] - (double)a[1]), (double)a[3] + t * ((double)b[3] - (double)a[3]));
+        }
+    }
+    if (n == 0) return false;
+    if (unbounded) { xmin = ymin = -1e300; xmax = ymax = 1e300; }
+    const double half = 0.5 * (double)res;
+    double fx0 = __builtin_floor((xmin + 1.0) * half - 0.5) - 1.0, fx1 = __builtin_ceil((xmax + 1.0) * half - 0.5) + 1.0;
+    double fy0 = __builtin_floor((ymin + 1.0) * half - 0.5) - 1.0, fy1 = __builtin_ceil((ymax + 1.0) * half - 0.5) + 1.0;
+    if (!(fx0 > 0.0)) fx0 = 0.0;
+    if (!(fy0 > 0.0)) fy0 = 0.0;
+    if (!(fx1 < (double)(res - 1))) fx1 = (double)(res - 1);
+    if (!(fy1 < (double)(res - 1))) fy1 = (double)(res - 1);
+    if (fx0 > fx1 || fy0 > fy1) return false;
+    bx0 = (int)fx0; by0 = (int)fy0; bx1 = (int)fx1; by1 = (int)fy1;
+    return true;
+}
+
+VKR_DEV size_t depth_texel_index(int res, int i, int j, bool tiled)
+{
+    if (!tiled) return (size_t)j * res + i;
+    return (size_t)(((unsigned)j >> 2) * ((unsigned)res >> 3) + ((unsigned)i >> 3)) * 32u + ((unsigned)j & 3u) * 8u + ((unsigned)i & 7u);
+}
+
+// One triangle into one res x res depth image; world = corners' world positions (point lights) or null.
+VKR_DEV void shadow_raster(const float (&clip)[3][4], const float (*world)[4], const float *light_pos, float inv_far, int res, bool tiled, float *img)
+{
+    const double x0 = clip[0][0], y0 = clip[0][1], w0 = clip[0][3], x1 = clip[1][0], y1 = clip[1][1], w1 = clip[1][3], x2 = clip[2][0], y2 = clip[2][1], w2 = clip[2][3];
+    STri t;
+    t.a[0] = y1 * w2 - w1 * y2; t.b[0] = w1 * x2 - x1 * w2; t.c[0] = x1 * y2 - y1 * x2;
+    t.a[1] = y2 * w0 - w2 * y0; t.b[1] = w2 * x0 - x2 * w0; t.c[1] = x2 * y0 - y2 * x0;
+    t.a[2] = y0 * w1 - w0 * y1; t.b[2] = w0 * x1 - x0 * w1; t.c[2] = x0 * y1 - y0 * x1;
+    t.z[0] = clip[0][2]; t.z[1] = clip[1][2]; t.z[2] = clip[2][2];
+    t.D = __builtin_fma(w0, t.c[0], __builtin_fma(y0, t.b[0], x0 * t.a[0]));
+    if (!(t.D > 0.0)) return;  // front faces and degenerate triangles are culled
+    int bx0, by0, bx1, by1;
+    if (!shadow_bbox(clip, res, bx0, by0, bx1, by1)) return;
+    const double sc = 2.0 / (double)res;
+    for (int j = by0; j <= by1; j++) {
+        const double yn = __builtin_fma((double)j + 0.5, sc, -1.0);
+        for (int i = bx0; i <= bx1; i++) {
+            const double xn = __builtin_fma((double)i + 0.5, sc, -1.0);
+            const double e0 = s_edge(t, 0, xn, yn), e1 = s_edge(t, 1, xn, yn), e2 = s_edge(t, 2, xn, yn);
+            const double s = (e0 + e1) + e2;
+            if (!(e0 >= 0.0 && e1 >= 0.0 && e2 >= 0.0 && s > 0.0)) continue;
+            const double zs = __builtin_fma(e2, t.z[2], __builtin_fma(e1, t.z[1], e0 * t.z[0]));
+            if (!(zs >= 0.0 && zs <= t.D)) continue;
+            float depth;
+            if (world) {  // point_shadow.frag:11-16 on the interpolated world position
+                float pw[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                    pw[k] = (float)(__builtin_fma(e2, (double)world[2][k], __builtin_fma(e1, (double)world[1][k], e0 * (double)world[0][k])) / s);
+                const f3 d = mk3(pw[0] - light_pos[0], pw[1] - light_pos[1], pw[2] - light_pos[2]);
+                depth = sqrt_rn(dot3(d, d)) * inv_far;
+            } else {
+                depth = (float)(zs / t.D) + 0.0f;  // z / w of the fixed-function pipeline (-0 becomes +0)
+            }
+            if (depth < 1.0f)  // CompareOp.Less against the cleared 1.0 and every earlier write; depth >= 0 here
+                atomicMin((unsigned int *)(img + depth_texel_index(res, i, j, tiled)), __builtin_bit_cast(unsigned int, depth));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void point_shadow_kernel(const ShadowParams p)
+{
+    __shared__ float s_m[6][16];
+    const int li = blockIdx.y;
+    const float *lp = p.lights + (size_t)li * 23 + 16;
+    const float eye[3] = {lp[0], lp[1], lp[2]};
+    if (threadIdx.x < 96) shadow_face_matrix_elem(eye, threadIdx.x >> 4, p.far_plane, threadIdx.x & 15, s_m[threadIdx.x >> 4]);
+    __syncthreads();
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= p.n_tris) return;
+    float world[3][4];
+    const unsigned vmax = (unsigned)p.n_verts - 1u;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float *v = p.positions + 3 * (size_t)min(p.indices[3 * t + k], vmax);
+        const float v4[4] = {v[0], v[1], v[2], 1.0f};
+        mat4_vec4(p.model, v4, world[k]);  // point_shadow.vert:12
+    }
+    const float inv_far = rcp_rn(p.far_plane);
+    const size_t face_texels = (size_t)p.res * p.res;
+    for (int face = 0; face < 6; face++) {
+        float clip[3][4];
+#pragma unroll
+        for (int k = 0; k < 3; k++) mat4_vec4(s_m[face], world[k], clip[k]);  // point_shadow.geom:20
+        shadow_raster(clip, world, eye, inv_far, p.res, p.tiled != 0, p.out + ((size_t)li * 6 + face) * face_texels);
+    }
+}
+
+__global__ __launch_bounds__(256) void dir_shadow_kernel(const ShadowParams p)
+{
+    __shared__ float s_mvp[16];
+    if (threadIdx.x < 16) s_mvp[threadIdx.x] = mat4_mul_elem(p.model, p.light_space, threadIdx.x >> 2, threadIdx.x & 3);  // depth.vert:13
+    __syncthreads();
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= p.n_tris) return;
+    float clip[3][4];
+    const unsigned vmax = (unsigned)p.n_verts - 1u;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float *v = p.positions + 3 * (size_t)min(p.indices[3 * t + k], vmax);
+        const float v4[4] = {v[0], v[1], v[2], 1.0f};
+        mat4_vec4(s_mvp, v4, clip[k]);
+    }
+    shadow_raster(clip, nullptr, nullptr, 0.0f, p.res, false, p.out);
+}
+
+__global__ __launch_bounds__(256) void fill_depth_kernel(float4 *out, size_t n4)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) out[i] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+}
+
+static int32_t check_draws(const char *who, const VkrMeshDraw *draws, int32_t n_draws)
+{
+    VKR_REQUIRE(n_draws >= 0 && (n_draws == 0 || draws), "%s: draws missing", who);
+    for (int d = 0; d < n_draws; d++)
+        VKR_REQUIRE(draws[d].positions && draws[d].indices && draws[d].n_verts > 0 && draws[d].n_tris >= 0, "%s: draw %d has no mesh", who, d);
+    return VKR_OK;
+}
+
+static void fill_params(ShadowParams &p, const VkrMeshDraw &d)
+{
+    p.positions = d.positions; p.indices = d.indices; p.n_verts = d.n_verts; p.n_tris = d.n_tris;
+    for (int i = 0; i < 16; i++) p.model[i] = d.model[i];
+}
+
+}  // namespace vkr
+
+extern "C" int32_t vkr_point_shadow_maps(const VkrPointShadowArgs *a, void *stream)
+{
+    using namespace vkr;
+    VKR_REQUIRE(a != nullptr, "vkr_point_shadow_maps: args is null");
+    int32_t rc = check_draws("vkr_point_shadow_maps", a->draws, a->n_draws);
+    if (rc != VKR_OK) return rc;
+    VKR_REQUIRE(a->n_lights >= 0 && a->n_lights <= 65535 && (a->n_lights == 0 || a->lights), "vkr_point_shadow_maps: lights missing or too many");
+    VKR_REQUIRE(a->res > 0 && a->res <= 8192 && a->res % 2 == 0, "vkr_point_shadow_maps: face size %d (even, at most 8192)", a->res);
+    VKR_REQUIRE(a->far_plane > 1.0f, "vkr_point_shadow_maps: far plane %g must lie beyond the near plane at 1", (double)a->far_plane);
+    VKR_REQUIRE(a->layout == VKR_CUBE_LAYOUT_LINEAR || (a->layout == VKR_CUBE_LAYOUT_TILED_8X4 && a->res % 8 == 0), "vkr_point_shadow_maps: layout %d not usable with face size %d", a->layout, a->res);
+    VKR_REQUIRE(a->out != nullptr, "vkr_point_shadow_maps: output is null");
+    if (a->n_lights == 0) return VKR_OK;
+    const size_t n4 = (size_t)a->n_lights * 6 * a->res * a->res / 4;
+    hipLaunchKernelGGL(fill_depth_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, as_stream(stream), (float4 *)a->out, n4);  // clear value 1.0
+    ShadowParams p;
+    p.lights = (const float *)a->lights;
+    p.res = a->res; p.far_plane = a->far_plane; p.tiled = a->layout == VKR_CUBE_LAYOUT_TILED_8X4; p.out = a->out;
+    for (int i = 0; i < 16; i++) p.light_space[i] = 0.0f;
+    for (int d = 0; d < a->n_draws; d++) {
+        if (a->draws[d].n_tris == 0) continue;
+        fill_params(p, a->draws[d]);
+        hipLaunchKernelGGL(point_shadow_kernel, dim3((unsigned)((p.n_tris + 255) / 256), (unsigned)a->n_lights), dim3(256), 0, as_stream(stream), p);
+    }
+    return launch_status("vkr_point_shadow_maps");
+}
+
+extern "C" int32_t vkr_dir_shadow_map(const VkrDirShadowArgs *a, void *stream)
+{
+    using namespace vkr;
+    VKR_REQUIRE(a != nullptr, "vkr_dir_shadow_map: args is null");
+    int32_t rc = check_draws("vkr_dir_shadow_map", a->draws, a->n_draws);
+    if (rc != VKR_OK) return rc;
+    VKR_REQUIRE(a->res > 0 && a->res <= 16384 && a->res % 2 == 0, "vkr_dir_shadow_map: map size %d (even, at most 16384)", a->res);
+    VKR_REQUIRE(a->out != nullptr, "vkr_dir_shadow_map: output is null");
+    const size_t n4 = (size_t)a->res * a->res / 4;
+    hipLaunchKernelGGL(fill_depth_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, as_stream(stream), (float4 *)a->out, n4);
+    ShadowParams p;
+    p.lights = nullptr;
+    p.res = a->res; p.far_plane = 0.0f; p.tiled = 0; p.out = a->out;
+    for (int i = 0; i < 16; i++) p.light_space[i] = a->light_space[i];
+    for (int d = 0; d < a->n_draws; d++) {
+        if (a->draws[d].n_tris == 0) continue;
+        fill_params(p, a->draws[d]);
+        hipLaunchKernelGGL(dir_shadow_kernel, dim3((unsigned)((p.n_tris + 255) / 256)), dim3(256), 0, as_stream(stream), p);
+    }
+    return launch_status("vkr_dir_shadow_map");
+}

@@ -100,6 +100,49 @@ def light_coverage(f: DeviceFrame, verts: torch.Tensor, indices: torch.Tensor,
     return masks
 
 
+def _mesh_draws(draws):
+    """draws: list of (positions [n,3] float32, triangles [m,3] int32, model 16 floats), tensors on the device."""
+    arr = (_lib.MeshDraw * len(draws))()
+    for k, (pos, tri, model) in enumerate(draws):
+        assert pos.dtype == torch.float32 and tri.dtype == torch.int32 and pos.is_contiguous() and tri.is_contiguous()
+        arr[k].positions, arr[k].n_verts = pos.data_ptr(), pos.shape[0]
+        arr[k].indices, arr[k].n_tris = tri.data_ptr(), tri.shape[0]
+        arr[k].model[:] = [float(v) for v in np.asarray(model, dtype=np.float32).ravel()]
+    return arr
+
+
+def point_shadow_maps(draws, lights: torch.Tensor, n_lights: int, res: int, far_plane: float = 25.0,
+                      tiled: bool | None = None) -> tuple[torch.Tensor, int]:
+    """The point-shadow passes: (depth cubes float32 [n_lights, 6, res, res], layout).  `lights` is the
+    device LightInfo array of a DeviceFrame; `tiled` None: 8x4-texel tiles whenever res allows."""
+    lib = _lib.load()
+    if tiled is None:
+        tiled = res % 8 == 0
+    out = torch.empty((n_lights, 6, res, res), dtype=torch.float32, device=lights.device)
+    arr = _mesh_draws(draws)
+    a = _lib.PointShadowArgs()
+    a.draws, a.n_draws = arr, len(draws)
+    a.lights, a.n_lights = _ptr(lights), n_lights
+    a.res, a.far_plane = res, far_plane
+    a.layout = _lib.CUBE_LAYOUT_TILED_8X4 if tiled else _lib.CUBE_LAYOUT_LINEAR
+    a.out = _ptr(out)
+    _lib.check(lib.vkr_point_shadow_maps(C.byref(a), _stream()))
+    return out, a.layout
+
+
+def dir_shadow_map(draws, light_space, res: int, device) -> torch.Tensor:
+    """The directional depth pass: float32 [res, res]."""
+    lib = _lib.load()
+    out = torch.empty((res, res), dtype=torch.float32, device=device)
+    arr = _mesh_draws(draws)
+    a = _lib.DirShadowArgs()
+    a.draws, a.n_draws = arr, len(draws)
+    a.light_space[:] = [float(v) for v in np.asarray(light_space, dtype=np.float32).ravel()]
+    a.res, a.out = res, _ptr(out)
+    _lib.check(lib.vkr_dir_shadow_map(C.byref(a), _stream()))
+    return out
+
+
 def tile_depth_cubes(linear: torch.Tensor) -> torch.Tensor:
     """[..., res, res] float32 depth faces, row-major -> the same faces as 8x4-texel tiles (new tensor)."""
     lib = _lib.load()

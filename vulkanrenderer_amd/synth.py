@@ -116,6 +116,42 @@ def make_sphere_mesh(segments: int = 32, rings: int = 16):
     return v, t
 
 
+def height_field(x, z):
+    """The synthetic scene's surface: y = 0.3 sin(1.7 x) cos(1.3 z)."""
+    return 0.3 * np.sin(1.7 * x) * np.cos(1.3 * z)
+
+
+def make_scene_mesh(n: int = 64, thickness: float = 0.3, extent: float = 3.0):
+    """The height field over [-extent, extent]^2 as a closed slab (top surface, a bottom `thickness` below,
+    side walls), counter-clockwise seen from outside, so that a shadow pass that culls front faces keeps its
+    far side.  Returns (verts [2(n+1)^2, 3] f32, triangles [m, 3] u32)."""
+    g = np.linspace(-extent, extent, n + 1)
+    xx, zz = np.meshgrid(g, g, indexing="xy")          # [row z, col x]
+    top = np.stack([xx, height_field(xx, zz), zz], -1).reshape(-1, 3)
+    bottom = top - np.array([0.0, thickness, 0.0])
+    verts = np.concatenate([top, bottom]).astype(np.float32)
+    nb = (n + 1) * (n + 1)
+    idx = lambda r, c: r * (n + 1) + c
+    tris = []
+    for r in range(n):
+        for c in range(n):
+            a, b, cc, d = idx(r, c), idx(r, c + 1), idx(r + 1, c), idx(r + 1, c + 1)
+            tris += [(a, cc, b), (b, cc, d)]                       # top: normal +y
+            tris += [(nb + a, nb + b, nb + cc), (nb + b, nb + d, nb + cc)]  # bottom: normal -y
+    for k in range(n):
+        for (p, q) in ((idx(0, k), idx(0, k + 1)), (idx(n, k + 1), idx(n, k)), (idx(k + 1, 0), idx(k, 0)), (idx(k, n), idx(k + 1, n))):
+            tris += [(p, q, nb + q), (p, nb + q, nb + p)]          # walls (orientation fixed below)
+    t = np.asarray(tris, dtype=np.uint32)
+    v = verts.astype(np.float64)
+    nrm = np.cross(v[t[:, 1]] - v[t[:, 0]], v[t[:, 2]] - v[t[:, 0]])
+    centre = np.array([0.0, -0.5 * thickness, 0.0])
+    mid = (v[t[:, 0]] + v[t[:, 1]] + v[t[:, 2]]) / 3.0
+    walls = np.arange(len(t)) >= 4 * n * n
+    flip = walls & ((nrm * (mid - centre)).sum(-1) < 0)
+    t[flip] = t[flip][:, [0, 2, 1]]
+    return verts, t
+
+
 def default_scene_info() -> np.ndarray:
     """SceneInfo of the reference's demo frame (Program.cs:84,120-132)."""
     s = np.zeros((), dtype=SCENE_DTYPE)
