@@ -160,6 +160,30 @@ def time_coverage(f, dev_frame, renderer, device) -> dict:
     return out
 
 
+def time_shadow_pass(f, dev_frame, device) -> dict:
+    """The passes that make the shadow maps (VulkanRenderer.cs:325-376, 406-428), on the synthetic scene's
+    mesh: a closed slab under the height field, 129^2 grid.  Not part of a step (the benchmark frame keeps its
+    synthetic maps resident); what a frame with moving lights would add."""
+    import torch
+    from vulkanrenderer_amd import passes as P, synth
+    verts, tris = synth.make_scene_mesh(128)
+    draws = [(torch.from_numpy(verts).to(device), torch.from_numpy(tris.astype(np.int32)).to(device), np.eye(4))]
+    res, dres, nl = f.cube_shadow.shape[-1], f.dir_shadow.shape[-1], len(f.lights)
+
+    def timed(fn, reps=3):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    return {"point_shadow_ms": round(timed(lambda: P.point_shadow_maps(draws, dev_frame.lights, nl, res)), 4),
+            "dir_shadow_ms": round(timed(lambda: P.dir_shadow_map(draws, f.scene["light_space_matrix"], dres, device)), 4),
+            "config": f"{nl} lights x 6 x {res}^2 D32F (written as 8x4 tiles) + {dres}^2 directional map; mesh {len(verts)} vertices, {len(tris)} triangles"}
+
+
 def measured_traffic(lights: int, cube_res: int, dir_res: int) -> dict:
     """HBM-side bytes per launch from the committed rocprofv3 counter passes (profiles/r1_traffic.json);
     counters cannot be read from inside this process, so the figures apply only to the workload they
@@ -207,7 +231,7 @@ def main() -> None:
     ap.add_argument("--dir-res", type=int, default=DIR_RES)
     ap.add_argument("--cpu-rows", type=int, default=None, help="rows of the frame the CPU baseline shades (default: all; 0 = skip)")
     ap.add_argument("--no-ibl", action="store_true", help="skip the IBL precompute timing")
-    ap.add_argument("--no-coverage", action="store_true", help="skip the light-volume coverage timing")
+    ap.add_argument("--no-coverage", action="store_true", help="skip the light-volume coverage and shadow-pass timings")
     args = ap.parse_args()
     WIDTH, HEIGHT = args.width, args.height
     args.cpu_rows = HEIGHT if args.cpu_rows is None else min(args.cpu_rows, HEIGHT)
@@ -337,6 +361,7 @@ def main() -> None:
                                  "bloom_v_frac_of_measured": round(20 * px / (kernel_ms["bloomv_post"] * 1e-3) / 1e9 / copy.value, 4)}
     if world == 1 and not args.no_coverage:
         out["light_volume_coverage"] = time_coverage(f, dev_frame, renderer, device)
+        out["shadow_pass"] = time_shadow_pass(f, dev_frame, device)
     if not args.no_ibl:
         out["ibl_precompute"] = time_ibl(device)
     if world == 1 and args.cpu_rows > 0:

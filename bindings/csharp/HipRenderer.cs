@@ -7,6 +7,7 @@
 //
 // Not compiled in this repository (no .NET SDK in the build image); it is declarative on purpose.
 using System.Runtime.InteropServices;
+using Silk.NET.Maths;
 
 namespace Renderer;
 
@@ -30,6 +31,8 @@ internal static unsafe class Native
     [DllImport(Lib)] public static extern int vkr_update_scene_info(nint ctx, in SceneInfo info);
     [DllImport(Lib)] public static extern int vkr_set_lights(nint ctx, LightInfo* lights, int n, int coverageMode);
     [DllImport(Lib)] public static extern int vkr_set_light_volume_mesh(nint ctx, float* verts, int nVerts, uint* indices, int nTris);
+    [DllImport(Lib)] public static extern int vkr_create_mesh(nint ctx, float* positions, int nVerts, uint* indices, int nTris, out int mesh);
+    [DllImport(Lib)] public static extern int vkr_draw_model(nint ctx, int mesh, in Matrix4X4<float> model);
     [DllImport(Lib)] public static extern int vkr_begin_frame(nint ctx);
     [DllImport(Lib)] public static extern int vkr_end_frame(nint ctx);
     [DllImport(Lib)] public static extern int vkr_upload_gbuffer(nint ctx, void* albedo, void* normal, void* arm, void* position);
@@ -70,6 +73,14 @@ public sealed unsafe class HipRenderer : IDisposable
         Check(Native.vkr_set_lights(ctx, infos, Lights.Count, hasVolumeMesh ? 1 : 0));   // 1 = VKR_COVERAGE_MESH
         Check(Native.vkr_end_frame(ctx));
     }
+
+    // Mesh.cs keeps positions and indices on the device; DrawModel is VulkanRenderer.cs:630-633
+    public int CreateMesh(float* positions, int nVerts, uint* indices, int nTris)
+    {
+        Check(Native.vkr_create_mesh(ctx, positions, nVerts, indices, nTris, out int mesh));
+        return mesh;
+    }
+    public void DrawModel(int mesh, Matrix4X4<float> modelMatrix) => Check(Native.vkr_draw_model(ctx, mesh, modelMatrix));
 
     // sphereMesh of the reference (VulkanRenderer.cs:78,269): positions and indices of the light volume
     public void SetLightVolumeMesh(float* verts, int nVerts, uint* indices, int nTris)

@@ -282,7 +282,14 @@ VKR_EXPORT int32_t vkr_begin_frame(vkr_ctx *ctx);                               
 VKR_EXPORT int32_t vkr_end_frame(vkr_ctx *ctx);
 VKR_EXPORT int32_t vkr_current_frame(vkr_ctx *ctx);
 
-/* Inputs the out-of-scope geometry / shadow passes would have produced for the current frame. */
+/* Meshes and the frame's draw calls.  vkr_create_mesh keeps a mesh on the device (Mesh.cs); vkr_draw_model is
+ * DrawModel (VulkanRenderer.cs:630-633): it queues the mesh with a model matrix between BeginFrame and EndFrame.
+ * When a frame has draw calls, EndFrame renders the point-light depth cubes and the directional depth map from
+ * them (VulkanRenderer.cs:325-376, 406-428) before the composition pass; otherwise uploaded maps are used. */
+VKR_EXPORT int32_t vkr_create_mesh(vkr_ctx *ctx, const float *positions, int32_t n_verts, const uint32_t *indices, int32_t n_tris, int32_t *mesh_out);
+VKR_EXPORT int32_t vkr_draw_model(vkr_ctx *ctx, int32_t mesh, const float *model16);
+
+/* Inputs the out-of-scope geometry pass (and, without draw calls, the shadow passes) would have produced for the current frame. */
 VKR_EXPORT int32_t vkr_upload_gbuffer(vkr_ctx *ctx, const void *albedo, const void *normal, const void *arm, const void *position);
 VKR_EXPORT int32_t vkr_upload_background(vkr_ctx *ctx, const void *rgba16f_or_null);
 VKR_EXPORT int32_t vkr_upload_dir_shadow(vkr_ctx *ctx, const float *depth);

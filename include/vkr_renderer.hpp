@@ -81,6 +81,15 @@ public:
         check(vkr_set_lights(ctx_, infos.data(), (int32_t)infos.size(), has_volume_mesh_ ? VKR_COVERAGE_MESH : VKR_COVERAGE_FULLSCREEN));
         check(vkr_end_frame(ctx_));
     }
+    // Mesh.cs / VulkanRenderer.DrawModel (VulkanRenderer.cs:630-633): with draw calls in a frame, EndFrame renders
+    // the shadow maps from them.
+    int32_t CreateMesh(const float *positions, int32_t n_verts, const uint32_t *indices, int32_t n_tris)
+    {
+        int32_t mesh = -1;
+        check(vkr_create_mesh(ctx_, positions, n_verts, indices, n_tris, &mesh));
+        return mesh;
+    }
+    void DrawModel(int32_t mesh, const float (&model_matrix)[16]) { check(vkr_draw_model(ctx_, mesh, model_matrix)); }
     // The reference's sphereMesh (VulkanRenderer.cs:78,269): once set, each light's draw touches only the
     // pixels its volume covers, as the reference's rasterised volumes do.
     void SetLightVolumeMesh(const float *verts, int32_t n_verts, const uint32_t *indices, int32_t n_tris)

@@ -596,3 +596,41 @@ def test_generated_shadow_maps_feed_the_shading_pass(gpu, oracle):
 def dataclasses_replace(f):
     import dataclasses
     return dataclasses.replace(f)
+
+
+def test_renderer_draw_calls_make_the_shadow_maps(gpu, oracle):
+    """Layer 2: CreateMesh + DrawModel between BeginFrame and EndFrame; EndFrame renders the depth cubes and
+    the directional map from the draw calls and shades with them (VulkanRenderer.EndFrame's order)."""
+    from vulkanrenderer_amd.renderer import HipRenderer
+    w, h, nl = 112, 64, 3
+    slab = synth.make_scene_mesh(20)
+    ball = synth.make_sphere_mesh(12, 6)
+    model = np.diag([0.5, 0.5, 0.5, 1.0]); model[3, :3] = (-0.8, 0.8, 0.6)
+    f = synth.make_frame(95, w, h, nl, 32, 64, irr_res=8, pref_res=16, lut_res=32)
+    draws = [(slab[0], slab[1], np.eye(4)), (ball[0], ball[1], model)]
+    f.cube_shadow = oracle.point_shadow_maps(draws, f.lights, 32)
+    f.dir_shadow = oracle.dir_shadow_map(draws, f.scene["light_space_matrix"], 64)
+    with HipRenderer(w, h, max_lights=4, dir_shadow_res=64, point_shadow_res=32, env_res=16,
+                     irradiance_res=8, prefilter_res=16, prefilter_mips=1, brdf_lut_res=32) as r:
+        r.UploadEnvironmentCubemap(synth.make_env_cube(np.random.default_rng(2), 16))
+        r.CreateIrradianceCubemap(); r.CreatePrefilteredCubemap(); r.CreateBRDFLUTTexture()
+        f.irradiance = r.Read(_lib.TARGET_IRRADIANCE)
+        f.prefilter = r.Read(_lib.TARGET_PREFILTER, mip=0)
+        f.brdf_lut = r.Read(_lib.TARGET_BRDF_LUT)
+        m_slab, m_ball = r.CreateMesh(*slab), r.CreateMesh(*ball)
+        with pytest.raises(_lib.VkrError):
+            r.DrawModel(m_slab, np.eye(4))          # outside a frame
+        want_c, want_t = oracle.shade(f)
+        for _ in range(2):                           # both frames in flight
+            frame = r.CurrentFrame
+            r.UpdateSceneInfo(f.scene)
+            r.UploadGBuffer(f.albedo, f.normal, f.arm, f.position)
+            r.SetLightInfos(f.lights)
+            r.BeginFrame()
+            r.DrawModel(m_slab, np.eye(4))
+            r.DrawModel(m_ball, model)
+            r._call(r._lib.vkr_end_frame)
+            assert_bits_equal(r.Read(_lib.TARGET_COLOR, frame), want_c, "colour")
+            assert_bits_equal(r.Read(_lib.TARGET_THRESHOLD, frame), want_t, "threshold")
+        with pytest.raises(_lib.VkrError):
+            r.DrawModel(99, np.eye(4))

@@ -135,6 +135,8 @@ PROTOTYPES = {
     "vkr_update_scene_info": [_vp, C.POINTER(SceneInfo)],
     "vkr_set_lights": [_vp, _vp, _i32, _i32],
     "vkr_set_light_volume_mesh": [_vp, _vp, _i32, _vp, _i32],
+    "vkr_create_mesh": [_vp, _vp, _i32, _vp, _i32, C.POINTER(C.c_int32)],
+    "vkr_draw_model": [_vp, _i32, _vp],
     "vkr_begin_frame": [_vp],
     "vkr_end_frame": [_vp],
     "vkr_current_frame": [_vp],

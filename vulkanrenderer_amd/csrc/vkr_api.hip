@@ -52,6 +52,9 @@ struct vkr_ctx {
     float *mesh_verts = nullptr;    // light-volume mesh (vkr_set_light_volume_mesh)
     uint32_t *mesh_indices = nullptr;
     int mesh_n_verts = 0, mesh_n_tris = 0;
+    struct Mesh { float *positions; uint32_t *indices; int n_verts, n_tris; };
+    std::vector<Mesh> meshes;            // vkr_create_mesh
+    std::vector<VkrMeshDraw> draw_calls; // vkr_draw_model since the last BeginFrame (solidModelDrawCalls)
     bool cubes_tiled = false;       // point shadow cubes are stored VKR_CUBE_LAYOUT_TILED_8X4
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timing_valid = false;
@@ -102,6 +105,7 @@ static void destroy(vkr_ctx *c)
         if (f.lights) (void)hipFree(f.lights);
     }
     void *ibl[] = {c->env, c->env_tiled, c->irradiance, c->brdf_lut, c->cube_staging, c->mesh_verts, c->mesh_indices};
+    for (auto &m : c->meshes) { (void)hipFree(m.positions); (void)hipFree(m.indices); }
     for (void *p : ibl) if (p) (void)hipFree(p);
     for (void *p : c->prefilter) if (p) (void)hipFree(p);
     for (hipEvent_t e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -110,6 +114,7 @@ static void destroy(vkr_ctx *c)
 }
 
 static int32_t run_coverage(vkr_ctx *c, Frame &f);
+static int32_t run_shadow_passes(vkr_ctx *c, Frame &f);
 
 #define VKR_CTX(c)                                                   \
     VKR_REQUIRE((c) != nullptr, "%s: context is null", __func__);    \
@@ -134,6 +139,28 @@ static int32_t fill_shade_args(vkr_ctx *c, Frame &f, VkrShadeArgs &a)
     a.out_color = f.color; a.out_threshold = f.threshold;
     a.coverage_masks = f.coverage == VKR_COVERAGE_MESH ? f.coverage_buf : nullptr;
     return VKR_OK;
+}
+
+// The shadow render passes of EndFrame (VulkanRenderer.cs:325-376, 406-428) over the frame's draw calls.
+// Without draw calls the uploaded maps stay as they are.
+static int32_t run_shadow_passes(vkr_ctx *c, Frame &f)
+{
+    if (c->draw_calls.empty()) return VKR_OK;
+    VkrPointShadowArgs ps;
+    memset(&ps, 0, sizeof(ps));
+    ps.draws = c->draw_calls.data(); ps.n_draws = (int32_t)c->draw_calls.size();
+    ps.lights = f.lights; ps.n_lights = f.n_lights;
+    ps.res = c->cfg.point_shadow_res; ps.far_plane = 25.0f;  // VulkanRenderer.cs:331
+    ps.layout = c->cubes_tiled ? VKR_CUBE_LAYOUT_TILED_8X4 : VKR_CUBE_LAYOUT_LINEAR;
+    ps.out = f.cube_shadow;
+    int32_t rc = vkr_point_shadow_maps(&ps, c->stream);
+    if (rc != VKR_OK) return rc;
+    VkrDirShadowArgs ds;
+    memset(&ds, 0, sizeof(ds));
+    ds.draws = ps.draws; ds.n_draws = ps.n_draws;
+    memcpy(ds.light_space, f.scene.light_space_matrix, sizeof(ds.light_space));
+    ds.res = c->cfg.dir_shadow_res; ds.out = f.dir_shadow;
+    return vkr_dir_shadow_map(&ds, c->stream);
 }
 
 // The light-volume draws' coverage (what rasterising sphere.glb per light decides in the reference).
@@ -293,6 +320,7 @@ extern "C" int32_t vkr_begin_frame(vkr_ctx *c)
     VKR_CTX(c);
     if (c->in_frame) return fail(VKR_ERR_ORDER, "Tried to begin frame before previous frame was finished!");  // VulkanRenderer.cs:288
     c->in_frame = true;
+    c->draw_calls.clear();  // VulkanRenderer.cs:316
     return VKR_OK;
 }
 
@@ -325,6 +353,37 @@ extern "C" int32_t vkr_set_light_volume_mesh(vkr_ctx *c, const float *verts, int
     if (rc == VKR_OK) rc = upload(c, c->mesh_indices, indices, (size_t)n_tris * 12);
     if (rc != VKR_OK) return rc;
     c->mesh_n_verts = n_verts; c->mesh_n_tris = n_tris;
+    return VKR_OK;
+}
+
+extern "C" int32_t vkr_create_mesh(vkr_ctx *c, const float *positions, int32_t n_verts, const uint32_t *indices, int32_t n_tris, int32_t *mesh_out)
+{
+    VKR_CTX(c);
+    VKR_REQUIRE(positions && indices && mesh_out && n_verts > 0 && n_tris > 0, "vkr_create_mesh: mesh missing");
+    for (int64_t i = 0; i < (int64_t)n_tris * 3; i++)
+        VKR_REQUIRE(indices[i] < (uint32_t)n_verts, "vkr_create_mesh: index %u at %lld is outside the %d vertices", indices[i], (long long)i, n_verts);
+    vkr_ctx::Mesh m = {nullptr, nullptr, n_verts, n_tris};
+    VKR_HIP_CHECK(hipMalloc((void **)&m.positions, (size_t)n_verts * 12));
+    hipError_t e = hipMalloc((void **)&m.indices, (size_t)n_tris * 12);
+    int32_t rc = e == hipSuccess ? upload(c, m.positions, positions, (size_t)n_verts * 12) : fail(VKR_ERR_HIP, "vkr_create_mesh: %s", hipGetErrorString(e));
+    if (rc == VKR_OK) rc = upload(c, m.indices, indices, (size_t)n_tris * 12);
+    if (rc != VKR_OK) { (void)hipFree(m.positions); if (m.indices) (void)hipFree(m.indices); return rc; }
+    c->meshes.push_back(m);
+    *mesh_out = (int32_t)c->meshes.size() - 1;
+    return VKR_OK;
+}
+
+extern "C" int32_t vkr_draw_model(vkr_ctx *c, int32_t mesh, const float *model16)
+{
+    VKR_CTX(c);
+    VKR_REQUIRE(mesh >= 0 && mesh < (int32_t)c->meshes.size(), "vkr_draw_model: unknown mesh %d", mesh);
+    VKR_REQUIRE(model16 != nullptr, "vkr_draw_model: model matrix is null");
+    if (!c->in_frame) return fail(VKR_ERR_ORDER, "vkr_draw_model: call between BeginFrame and EndFrame");
+    const vkr_ctx::Mesh &m = c->meshes[mesh];
+    VkrMeshDraw d;
+    d.positions = m.positions; d.n_verts = m.n_verts; d.indices = m.indices; d.n_tris = m.n_tris;
+    memcpy(d.model, model16, sizeof(d.model));
+    c->draw_calls.push_back(d);
     return VKR_OK;
 }
 
@@ -452,6 +511,7 @@ extern "C" int32_t vkr_pass_composition(vkr_ctx *c)
     VkrShadeArgs a;
     int32_t rc = fill_shade_args(c, c->frames[c->frame], a);
     if (rc != VKR_OK) return rc;
+    if ((rc = run_shadow_passes(c, c->frames[c->frame])) != VKR_OK) return rc;
     if ((rc = run_coverage(c, c->frames[c->frame])) != VKR_OK) return rc;
     return vkr_shade(&a, c->stream);
 }
@@ -483,7 +543,8 @@ extern "C" int32_t vkr_end_frame(vkr_ctx *c)
     int32_t rc = fill_shade_args(c, f, a);
     if (rc != VKR_OK) return rc;
     VKR_HIP_CHECK(hipEventRecord(c->ev[0], c->stream));
-    if ((rc = run_coverage(c, f)) != VKR_OK) return rc;  // counted with the composition pass, whose draws it stands for
+    if ((rc = run_shadow_passes(c, f)) != VKR_OK) return rc;
+    if ((rc = run_coverage(c, f)) != VKR_OK) return rc;  // both counted with the composition pass in the timing
     if ((rc = vkr_shade(&a, c->stream)) != VKR_OK) return rc;
     VKR_HIP_CHECK(hipEventRecord(c->ev[1], c->stream));
     VkrBloomArgs b1 = bloom_args(c, f, 1);

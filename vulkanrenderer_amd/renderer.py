@@ -126,6 +126,21 @@ class HipRenderer:
         infos = np.ascontiguousarray(infos)
         self._call(self._lib.vkr_set_lights, _host_ptr(infos) if len(infos) else C.c_void_p(0), len(infos), coverage)
 
+    def CreateMesh(self, verts: np.ndarray, triangles: np.ndarray) -> int:
+        """Keeps a mesh on the device (Mesh.cs); returns its handle for DrawModel."""
+        verts = np.ascontiguousarray(verts, dtype=np.float32)
+        triangles = np.ascontiguousarray(triangles, dtype=np.uint32)
+        handle = C.c_int32(-1)
+        self._call(self._lib.vkr_create_mesh, _host_ptr(verts), len(verts), _host_ptr(triangles), len(triangles), C.byref(handle))
+        return handle.value
+
+    def DrawModel(self, mesh: int, model_matrix) -> None:
+        """VulkanRenderer.DrawModel (VulkanRenderer.cs:630-633): queues a draw call for this frame; EndFrame then
+        renders the shadow maps from the frame's draw calls."""
+        m = np.ascontiguousarray(model_matrix, dtype=np.float32).ravel()
+        assert m.size == 16
+        self._call(self._lib.vkr_draw_model, mesh, _host_ptr(m))
+
     def SetLightVolumeMesh(self, verts: np.ndarray, triangles: np.ndarray) -> None:
         """The mesh each light volume is an instance of (the reference's sphereMesh, VulkanRenderer.cs:78,269);
         with it, SetLightInfos(..., COVERAGE_MESH) restricts each light's draw to the pixels its volume covers."""
