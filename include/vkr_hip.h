@@ -178,6 +178,33 @@ typedef struct VkrDirShadowArgs {
 } VkrDirShadowArgs;
 VKR_EXPORT int32_t vkr_dir_shadow_map(const VkrDirShadowArgs *args, void *stream);
 
+/* Geometry pass: replaces the gpass.vert / gpass.frag draws of VulkanRenderer.cs:378-404 (BACK faces culled,
+ * depth test LESS), producing the four RGBA16F G-buffer images vkr_shade reads.  Material images are
+ * single-level RGBA8 (albedo and ao/roughness/metalness _SRGB, normal map _UNORM: Texture.cs:21,
+ * Material.cs:20-22), sampled LINEAR / REPEAT. */
+typedef struct VkrTexture {
+    const void *rgba8;         /* device memory, height * width * 4 bytes */
+    int32_t width, height;
+} VkrTexture;
+typedef struct VkrGpassDraw {
+    const float *positions, *texcoords, *normals, *tangents;  /* device memory: 3, 2, 3, 3 floats per vertex (Mesh.cs vertex layout) */
+    int32_t n_verts;
+    const uint32_t *indices;   /* device memory, 3 per triangle, counter-clockwise seen from outside */
+    int32_t n_tris;
+    float model[16];           /* DrawCall.ModelMatrix */
+    VkrTexture albedo, normal, arm;  /* Model.Material */
+} VkrGpassDraw;
+typedef struct VkrGpassArgs {
+    const VkrGpassDraw *draws; int32_t n_draws;  /* host array, in submission order */
+    VkrSceneInfo scene;                          /* camera_view and camera_projection are read */
+    int32_t width, rows;                         /* the image: a strip of the frame */
+    int32_t frame_rows, row0;
+    void *albedo, *normal, *arm, *position;      /* device memory, RGBA16F rows*width texels each */
+    void *workspace; int64_t workspace_bytes;    /* device memory, at least vkr_gbuffer_workspace_bytes() */
+} VkrGpassArgs;
+VKR_EXPORT int64_t vkr_gbuffer_workspace_bytes(int32_t width, int32_t rows, int32_t n_draws);
+VKR_EXPORT int32_t vkr_gbuffer(const VkrGpassArgs *args, void *stream);
+
 /* Re-lays `n_faces` D32F faces of `res`^2 texels from VKR_CUBE_LAYOUT_LINEAR to
  * VKR_CUBE_LAYOUT_TILED_8X4 (res % 8 == 0; src and dst must not overlap).  No counterpart in the
  * reference, whose depth images are written tiled by the rasteriser. */

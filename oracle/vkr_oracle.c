@@ -1232,3 +1232,175 @@ ORC_API int orc_omp_threads(void)
     return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Geometry pass: gpass.vert / gpass.frag over the frame's draw calls (VulkanRenderer.cs:378-404),
+ * BACK faces culled, CCW front, depth test LESS, four RGBA16F targets cleared to
+ * (0,0,0,0), (0,0,0,1), (0,0,0,1), (0,0,0,1) (VulkanRenderer.cs:1155-1161; GraphicsPipeline.cs:71-73).
+ * Visibility is the rasteriser's and the depth test's: per pixel the covering front-facing
+ * triangle with the smallest depth z/w, the earlier draw (then the earlier triangle) winning a
+ * tie, as LESS does in submission order.  Coverage as in orc_light_coverage; vertex outputs are
+ * interpolated perspective-correctly, sum(Ei*ai)/sum(Ei), and rounded to binary32.
+ * Material textures are single-level RGBA8 images read through textureSampler: LINEAR, REPEAT
+ * (its anisotropic filtering is implementation-defined and not modelled); albedo and the
+ * ao/roughness/metalness image are _SRGB, the normal map _UNORM (Texture.cs:21, Material.cs:20-22). */
+
+typedef struct { const uint8_t *rgba8; int32_t width, height; } orc_texture;
+
+typedef struct {
+    const float *positions, *texcoords, *normals, *tangents;  /* 3, 2, 3, 3 floats per vertex */
+    int32_t n_verts;
+    const uint32_t *indices; int32_t n_tris;
+    float model[16];
+    orc_texture albedo, normal, arm;
+} orc_gpass_draw;
+
+typedef struct {
+    const orc_gpass_draw *draws; int32_t n_draws;
+    const orc_scene_info *scene;
+    int32_t width, rows, frame_rows, row0;
+    uint16_t *albedo, *normal, *arm, *position;   /* RGBA16F, rows * width texels each */
+} orc_gpass_args;
+
+typedef struct { float pos[4], uv[2], tbn[9], clip[4]; } gp_vertex;
+
+/* gpass.vert:24-35 */
+static void gpass_vertex(const orc_gpass_draw *d, const float *vp, uint32_t i, gp_vertex *o)
+{
+    const float p4[4] = {d->positions[3 * i], d->positions[3 * i + 1], d->positions[3 * i + 2], 1.0f};
+    mat4_vec4(d->model, p4, o->pos);
+    mat4_vec4(vp, o->pos, o->clip);   /* (proj * view) * outPosition */
+    o->uv[0] = d->texcoords[2 * i]; o->uv[1] = d->texcoords[2 * i + 1];
+    const float t4[4] = {d->tangents[3 * i], d->tangents[3 * i + 1], d->tangents[3 * i + 2], 0.0f};
+    const float n4[4] = {d->normals[3 * i], d->normals[3 * i + 1], d->normals[3 * i + 2], 0.0f};
+    float tw[4], nw[4];
+    mat4_vec4(d->model, t4, tw);
+    mat4_vec4(d->model, n4, nw);
+    v3 T = normalize3(v3_(tw[0], tw[1], tw[2]));
+    const v3 N = normalize3(v3_(nw[0], nw[1], nw[2]));
+    const float tn = dot3(T, N);
+    T = normalize3(v3_(T.x - tn * N.x, T.y - tn * N.y, T.z - tn * N.z));
+    const v3 B = v3_(fmaf(N.y, T.z, -(N.z * T.y)), fmaf(N.z, T.x, -(N.x * T.z)), fmaf(N.x, T.y, -(N.y * T.x)));
+    o->tbn[0] = T.x; o->tbn[1] = T.y; o->tbn[2] = T.z;
+    o->tbn[3] = B.x; o->tbn[4] = B.y; o->tbn[5] = B.z;
+    o->tbn[6] = N.x; o->tbn[7] = N.y; o->tbn[8] = N.z;
+}
+
+/* textureSampler on a single-level RGBA8 image: LINEAR, REPEAT; srgb: decode r,g,b before filtering */
+static void tex2d_rgba8_linear_repeat(const orc_texture *t, int srgb, float s, float tt, float *o4)
+{
+    const int w = t->width, h = t->height;
+    float x = s * (float)w - 0.5f, y = tt * (float)h - 0.5f;
+    float fx = floorf(x), fy = floorf(y);
+    float al = x - fx, be = y - fy;
+    int i0 = wrap_i((int)fx, w, 0), i1 = wrap_i((int)fx + 1, w, 0);
+    int j0 = wrap_i((int)fy, h, 0), j1 = wrap_i((int)fy + 1, h, 0);
+    float w00 = (1.0f - al) * (1.0f - be), w10 = al * (1.0f - be), w01 = (1.0f - al) * be, w11 = al * be;
+    const uint8_t *p00 = t->rgba8 + ((size_t)j0 * w + i0) * 4, *p10 = t->rgba8 + ((size_t)j0 * w + i1) * 4;
+    const uint8_t *p01 = t->rgba8 + ((size_t)j1 * w + i0) * 4, *p11 = t->rgba8 + ((size_t)j1 * w + i1) * 4;
+    for (int c = 0; c < 4; c++) {
+        float a, b, cc, d;
+        if (srgb && c < 3) { a = SRGB_LUT[p00[c]]; b = SRGB_LUT[p10[c]]; cc = SRGB_LUT[p01[c]]; d = SRGB_LUT[p11[c]]; }
+        else { a = (float)p00[c] * (1.0f / 255.0f); b = (float)p10[c] * (1.0f / 255.0f); cc = (float)p01[c] * (1.0f / 255.0f); d = (float)p11[c] * (1.0f / 255.0f); }
+        o4[c] = fmaf(w11, d, fmaf(w01, cc, fmaf(w10, b, w00 * a)));
+    }
+}
+
+ORC_API void orc_gbuffer(const orc_gpass_args *a)
+{
+    build_srgb_lut();
+    const size_t npx = (size_t)a->width * a->rows;
+    uint64_t *vis = (uint64_t *)malloc(npx * sizeof(uint64_t));   /* depth bits << 32 | triangle number */
+    for (size_t i = 0; i < npx; i++) vis[i] = ~0ull;
+    float vp[16];
+    mat4_mul(a->scene->camera_view, a->scene->camera_proj, vp);
+    const double sx = 2.0 / (double)a->width, sy = 2.0 / (double)a->frame_rows;
+    /* pass 1: visibility */
+    uint32_t base = 0;
+    for (int di = 0; di < a->n_draws; di++) {
+        const orc_gpass_draw *d = a->draws + di;
+        for (int t = 0; t < d->n_tris; t++) {
+            gp_vertex v[3];
+            float clip[3][4];
+            for (int k = 0; k < 3; k++) { gpass_vertex(d, vp, d->indices[3 * t + k], &v[k]); memcpy(clip[k], v[k].clip, sizeof(clip[k])); }
+            cov_tri tr;
+            cov_setup(clip[0], clip[1], clip[2], &tr);
+            if (!(tr.D < 0.0)) continue;            /* BACK faces (D > 0) and degenerate triangles are culled */
+            for (int i = 0; i < 3; i++) { tr.a[i] = -tr.a[i]; tr.b[i] = -tr.b[i]; tr.c[i] = -tr.c[i]; }
+            tr.D = -tr.D;
+            int bx0, by0, bx1, by1;
+            /* the bounding box helper works in texels of a square image: use it per axis */
+            {
+                int qx0, qy0, qx1, qy1, rx0, ry0, rx1, ry1;
+                if (!shadow_bbox(clip, a->width, &qx0, &qy0, &qx1, &qy1)) continue;
+                if (!shadow_bbox(clip, a->frame_rows, &rx0, &ry0, &rx1, &ry1)) continue;
+                bx0 = qx0; bx1 = qx1; by0 = ry0 - a->row0; by1 = ry1 - a->row0;
+                if (by0 < 0) by0 = 0;
+                if (by1 > a->rows - 1) by1 = a->rows - 1;
+                if (by0 > by1) continue;
+            }
+            for (int y = by0; y <= by1; y++) {
+                const double yn = fma((double)(a->row0 + y) + 0.5, sy, -1.0);
+                for (int x = bx0; x <= bx1; x++) {
+                    const double xn = fma((double)x + 0.5, sx, -1.0);
+                    const double e0 = cov_edge(&tr, 0, xn, yn), e1 = cov_edge(&tr, 1, xn, yn), e2 = cov_edge(&tr, 2, xn, yn);
+                    if (!(e0 >= 0.0 && e1 >= 0.0 && e2 >= 0.0 && (e0 + e1) + e2 > 0.0)) continue;
+                    const double zs = fma(e2, tr.z[2], fma(e1, tr.z[1], e0 * tr.z[0]));
+                    if (!(zs >= 0.0 && zs <= tr.D)) continue;
+                    const float depth = (float)(zs / tr.D) + 0.0f;
+                    uint32_t bits; memcpy(&bits, &depth, 4);
+                    const uint64_t key = ((uint64_t)bits << 32) | (uint64_t)(base + (uint32_t)t);
+                    uint64_t *o = vis + (size_t)y * a->width + x;
+                    if (key < *o) *o = key;
+                }
+            }
+        }
+        base += (uint32_t)d->n_tris;
+    }
+    /* pass 2: shade the visible triangle of every pixel (gpass.frag) */
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < a->rows; y++)
+        for (int x = 0; x < a->width; x++) {
+            const size_t p = (size_t)y * a->width + x;
+            uint16_t *oa = a->albedo + p * 4, *on = a->normal + p * 4, *om = a->arm + p * 4, *op = a->position + p * 4;
+            if (vis[p] == ~0ull) { /* clear values */
+                oa[0] = oa[1] = oa[2] = oa[3] = 0;
+                on[0] = on[1] = on[2] = 0; on[3] = 0x3C00;
+                om[0] = om[1] = om[2] = 0; om[3] = 0x3C00;
+                op[0] = op[1] = op[2] = 0; op[3] = 0x3C00;
+                continue;
+            }
+            uint32_t id = (uint32_t)(vis[p] & 0xFFFFFFFFu), b0 = 0;
+            int di = 0;
+            while (id - b0 >= (uint32_t)a->draws[di].n_tris) { b0 += (uint32_t)a->draws[di].n_tris; di++; }
+            const orc_gpass_draw *d = a->draws + di;
+            const int t = (int)(id - b0);
+            gp_vertex v[3];
+            for (int k = 0; k < 3; k++) gpass_vertex(d, vp, d->indices[3 * t + k], &v[k]);
+            cov_tri tr;
+            cov_setup(v[0].clip, v[1].clip, v[2].clip, &tr);
+            for (int i = 0; i < 3; i++) { tr.a[i] = -tr.a[i]; tr.b[i] = -tr.b[i]; tr.c[i] = -tr.c[i]; }
+            const double xn = fma((double)x + 0.5, sx, -1.0), yn = fma((double)(a->row0 + y) + 0.5, sy, -1.0);
+            const double e0 = cov_edge(&tr, 0, xn, yn), e1 = cov_edge(&tr, 1, xn, yn), e2 = cov_edge(&tr, 2, xn, yn);
+            const double s = (e0 + e1) + e2;
+#define GP_LERP(field, k) ((float)(fma(e2, (double)v[2].field[k], fma(e1, (double)v[1].field[k], e0 * (double)v[0].field[k])) / s))
+            const float u = GP_LERP(uv, 0), vv = GP_LERP(uv, 1);
+            float pos[4], tbn[9];
+            for (int k = 0; k < 4; k++) pos[k] = GP_LERP(pos, k);
+            for (int k = 0; k < 9; k++) tbn[k] = GP_LERP(tbn, k);
+#undef GP_LERP
+            float alb[4], nm[4], arm[4];
+            tex2d_rgba8_linear_repeat(&d->albedo, 1, u, vv, alb);
+            tex2d_rgba8_linear_repeat(&d->normal, 0, u, vv, nm);
+            tex2d_rgba8_linear_repeat(&d->arm, 1, u, vv, arm);
+            const v3 n = normalize3(v3_(fmaf(nm[0], 2.0f, -1.0f), fmaf(nm[1], 2.0f, -1.0f), fmaf(nm[2], 2.0f, -1.0f)));
+            /* mat3(T, B, N) * n */
+            const float wn[3] = {fmaf(tbn[6], n.z, fmaf(tbn[3], n.y, tbn[0] * n.x)),
+                                 fmaf(tbn[7], n.z, fmaf(tbn[4], n.y, tbn[1] * n.x)),
+                                 fmaf(tbn[8], n.z, fmaf(tbn[5], n.y, tbn[2] * n.x))};
+            for (int k = 0; k < 4; k++) { oa[k] = f2h(alb[k]); om[k] = f2h(arm[k]); op[k] = f2h(pos[k]); }
+            for (int k = 0; k < 3; k++) on[k] = f2h(wn[k]);
+            on[3] = 0x3C00;
+        }
+    free(vis);
+}

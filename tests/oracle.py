@@ -53,6 +53,22 @@ class DirShadowArgs(C.Structure):
     _fields_ = [("draws", C.c_void_p), ("n_draws", C.c_int32), ("light_space", C.c_void_p), ("res", C.c_int32), ("out", C.c_void_p)]
 
 
+class Texture(C.Structure):
+    _fields_ = [("rgba8", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class GpassDraw(C.Structure):
+    _fields_ = [("positions", C.c_void_p), ("texcoords", C.c_void_p), ("normals", C.c_void_p), ("tangents", C.c_void_p),
+                ("n_verts", C.c_int32), ("indices", C.c_void_p), ("n_tris", C.c_int32), ("model", C.c_float * 16),
+                ("albedo", Texture), ("normal", Texture), ("arm", Texture)]
+
+
+class GpassArgs(C.Structure):
+    _fields_ = [("draws", C.c_void_p), ("n_draws", C.c_int32), ("scene", C.c_void_p),
+                ("width", C.c_int32), ("rows", C.c_int32), ("frame_rows", C.c_int32), ("row0", C.c_int32),
+                ("albedo", C.c_void_p), ("normal", C.c_void_p), ("arm", C.c_void_p), ("position", C.c_void_p)]
+
+
 def build() -> None:
     subprocess.run(["make", "-C", ORACLE_DIR, "-s"], check=True)
 
@@ -179,6 +195,34 @@ def shadow_face_matrix(eye, face: int, far_plane: float = 25.0) -> np.ndarray:
     out = np.empty(16, dtype=np.float32)
     load().orc_shadow_face_matrix(_p(eye), face, C.c_float(far_plane), _p(out))
     return out.reshape(4, 4)
+
+
+def gbuffer(draws, scene: np.ndarray, width: int, rows: int, frame_rows: int | None = None, row0: int = 0):
+    """Geometry pass (gpass.vert/.frag).  draws: list of dicts with positions, texcoords, normals, tangents,
+    triangles, model and the RGBA8 images albedo, normal, arm [h, w, 4].  Returns (albedo, normal, arm,
+    position) uint16 [rows, width, 4]."""
+    arr = (GpassDraw * len(draws))()
+    keep = []
+    for k, d in enumerate(draws):
+        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+        pos, uv, nrm, tan = f32(d["positions"]), f32(d["texcoords"]), f32(d["normals"]), f32(d["tangents"])
+        tri = np.ascontiguousarray(d["triangles"], dtype=np.uint32)
+        tex = [np.ascontiguousarray(d[n], dtype=np.uint8) for n in ("albedo", "normal", "arm")]
+        keep += [pos, uv, nrm, tan, tri] + tex
+        arr[k].positions, arr[k].texcoords, arr[k].normals, arr[k].tangents = (x.ctypes.data for x in (pos, uv, nrm, tan))
+        arr[k].n_verts, arr[k].indices, arr[k].n_tris = len(pos), tri.ctypes.data, len(tri)
+        arr[k].model[:] = [float(v) for v in np.asarray(d["model"], dtype=np.float32).ravel()]
+        for field, t in zip(("albedo", "normal", "arm"), tex):
+            getattr(arr[k], field).rgba8 = t.ctypes.data
+            getattr(arr[k], field).width, getattr(arr[k], field).height = t.shape[1], t.shape[0]
+    scene = np.ascontiguousarray(scene).reshape(1)
+    out = [np.zeros((rows, width, 4), dtype=np.uint16) for _ in range(4)]
+    a = GpassArgs()
+    a.draws, a.n_draws, a.scene = C.addressof(arr), len(draws), _p(scene)
+    a.width, a.rows, a.frame_rows, a.row0 = width, rows, rows if frame_rows is None else frame_rows, row0
+    a.albedo, a.normal, a.arm, a.position = (_p(o) for o in out)
+    load().orc_gbuffer(C.byref(a))
+    return tuple(out)
 
 
 def shade(f, background: np.ndarray | None = None, rows: tuple[int, int] | None = None, coverage: np.ndarray | None = None):

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "vkr_hip.h")).read()
-    return sorted(set(re.findall(r"VKR_EXPORT\s+(?:const\s+char\s*\*|int32_t)\s*(vkr_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"VKR_EXPORT\s+(?:const\s+char\s*\*|int32_t|int64_t)\s*(vkr_\w+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -105,7 +105,9 @@ def test_ctypes_structs_have_the_headers_layout(tmp_path):
     import subprocess
     from vulkanrenderer_amd import _lib
     pairs = {"VkrShadeArgs": _lib.ShadeArgs, "VkrCoverageArgs": _lib.CoverageArgs, "VkrBloomArgs": _lib.BloomArgs,
-             "VkrBloomPostArgs": _lib.BloomPostArgs, "VkrSceneInfo": _lib.SceneInfo, "VkrLightInfo": _lib.LightInfo}
+             "VkrBloomPostArgs": _lib.BloomPostArgs, "VkrSceneInfo": _lib.SceneInfo, "VkrLightInfo": _lib.LightInfo,
+             "VkrMeshDraw": _lib.MeshDraw, "VkrPointShadowArgs": _lib.PointShadowArgs, "VkrDirShadowArgs": _lib.DirShadowArgs,
+             "VkrTexture": _lib.Texture, "VkrGpassDraw": _lib.GpassDraw, "VkrGpassArgs": _lib.GpassArgs}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "vkr_hip.h"', 'int main(void) {']
     for cname, ct in pairs.items():
         lines.append(f'  printf("{cname} %zu", sizeof({cname}));')

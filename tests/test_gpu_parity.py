@@ -634,3 +634,76 @@ def test_renderer_draw_calls_make_the_shadow_maps(gpu, oracle):
             assert_bits_equal(r.Read(_lib.TARGET_THRESHOLD, frame), want_t, "threshold")
         with pytest.raises(_lib.VkrError):
             r.DrawModel(99, np.eye(4))
+
+
+def _gpass_scene(w, h):
+    slab = synth.make_scene_mesh(20)
+    ball = synth.make_sphere_mesh(16, 8)
+    model = np.diag([0.7, 0.7, 0.7, 1.0]); model[3, :3] = (0.6, 0.8, -1.2)
+    draws = []
+    for k, ((verts, tris), m, scale) in enumerate(((slab, np.eye(4), 0.25), (ball, model, 0.5))):
+        uv, nrm, tan = synth.mesh_attributes(verts, tris, uv_scale=scale)
+        alb, nmap, arm = synth.make_material(np.random.default_rng(40 + k), 32 + 16 * k)
+        draws.append(dict(positions=verts, texcoords=uv, normals=nrm, tangents=tan, triangles=tris, model=m,
+                          albedo=alb, normal=nmap, arm=arm))
+    return draws
+
+
+def _gpass_device_draws(draws, gpu):
+    torch = _torch()
+    out = []
+    for d in draws:
+        dd = {k: torch.from_numpy(np.ascontiguousarray(d[k], dtype=np.float32)).to(gpu) for k in ("positions", "texcoords", "normals", "tangents")}
+        dd["triangles"] = torch.from_numpy(np.ascontiguousarray(d["triangles"]).astype(np.int32)).to(gpu)
+        for k in ("albedo", "normal", "arm"):
+            dd[k] = torch.from_numpy(np.ascontiguousarray(d[k])).to(gpu)
+        dd["model"] = d["model"]
+        out.append(dd)
+    return out
+
+
+@pytest.mark.parametrize("w,h,row0,frame_rows", [(192, 108, 0, 108), (157, 41, 30, 108)])
+def test_gbuffer_bit_exact(gpu, oracle, w, h, row0, frame_rows):
+    """vkr_gbuffer against the oracle's geometry pass: two draws with different materials, one occluding the
+    other; a whole frame and a strip of it."""
+    torch, P = _torch(), _passes()
+    draws = _gpass_scene(w, h)
+    scene = _camera_scene((2.0, 1.6, -4.0), aspect=w / frame_rows)
+    want = oracle.gbuffer(draws, scene, w, h, frame_rows, row0)
+    covered = want[0][..., 3] != 0
+    assert 0.2 < covered.mean() < 0.95
+    got = P.gbuffer(_gpass_device_draws(draws, gpu), scene, w, h, gpu, frame_rows, row0)
+    for name, g, wv in zip(("albedo", "normal", "arm", "position"), got, want):
+        assert_bits_equal(P.f16_bits(g), wv, f"G-buffer {name}")
+
+
+def test_whole_frame_from_meshes(gpu, oracle):
+    """Meshes in, image out: geometry pass, shadow passes, composition, bloom and tonemap all by the library,
+    against the same chain in the oracle."""
+    torch, P = _torch(), _passes()
+    w, h, nl = 160, 90, 3
+    draws = _gpass_scene(w, h)
+    f = synth.make_frame(77, w, h, nl, 32, 64, irr_res=8, pref_res=16, lut_res=32)
+    f.scene = _camera_scene((2.0, 1.6, -4.0), aspect=w / h)
+    f.albedo, f.normal, f.arm, f.position = oracle.gbuffer(draws, f.scene, w, h)
+    shadow_draws = [(d["positions"], d["triangles"], d["model"]) for d in draws]
+    f.cube_shadow = oracle.point_shadow_maps(shadow_draws, f.lights, 32)
+    f.dir_shadow = oracle.dir_shadow_map(shadow_draws, f.scene["light_space_matrix"], 64)
+    want = oracle.frame_chain(f)
+
+    dev = P.DeviceFrame.upload(f, gpu)
+    ddraws = _gpass_device_draws(draws, gpu)
+    ga, gn, gm, gp = P.gbuffer(ddraws, f.scene, w, h, gpu)
+    dev.albedo, dev.normal, dev.arm, dev.position = ga, gn, gm, gp
+    sdraws = [(d["positions"], d["triangles"], d["model"]) for d in ddraws]
+    dev.cube_shadow, dev.cube_layout = P.point_shadow_maps(sdraws, dev.lights, nl, 32)
+    dev.dir_shadow = P.dir_shadow_map(sdraws, f.scene["light_space_matrix"], 64, gpu)
+    color = torch.empty((h, w, 4), dtype=torch.float16, device=gpu)
+    thr, b1 = torch.empty_like(color), torch.empty_like(color)
+    ldr = torch.empty((h, w, 4), dtype=torch.uint8, device=gpu)
+    P.shade(dev, color, thr)
+    P.bloom_blur(thr, b1, True, _lib.WRAP_REPEAT)
+    P.bloomv_postprocess(b1, color, ldr)
+    assert_bits_equal(P.f16_bits(color), want["color"], "colour")
+    assert np.abs(ldr.cpu().numpy().astype(np.int32) - want["ldr"].astype(np.int32)).max() <= 1
+    assert (want["color"][..., :3] != 0).any()

@@ -86,6 +86,23 @@ class DirShadowArgs(C.Structure):
                 ("res", C.c_int32), ("out", C.c_void_p)]
 
 
+class Texture(C.Structure):
+    _fields_ = [("rgba8", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class GpassDraw(C.Structure):
+    _fields_ = [("positions", C.c_void_p), ("texcoords", C.c_void_p), ("normals", C.c_void_p), ("tangents", C.c_void_p),
+                ("n_verts", C.c_int32), ("indices", C.c_void_p), ("n_tris", C.c_int32), ("model", C.c_float * 16),
+                ("albedo", Texture), ("normal", Texture), ("arm", Texture)]
+
+
+class GpassArgs(C.Structure):
+    _fields_ = [("draws", C.POINTER(GpassDraw)), ("n_draws", C.c_int32), ("scene", SceneInfo),
+                ("width", C.c_int32), ("rows", C.c_int32), ("frame_rows", C.c_int32), ("row0", C.c_int32),
+                ("albedo", C.c_void_p), ("normal", C.c_void_p), ("arm", C.c_void_p), ("position", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+
+
 class BloomArgs(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("width", C.c_int32), ("rows", C.c_int32),
                 ("src_rows", C.c_int32), ("src_row_offset", C.c_int32), ("horizontal", C.c_int32),
@@ -119,6 +136,8 @@ PROTOTYPES = {
     "vkr_tile_depth_cubes": [_vp, _vp, C.c_int32, C.c_int32, _vp],
     "vkr_light_coverage": [C.POINTER(CoverageArgs), _vp],
     "vkr_point_shadow_maps": [C.POINTER(PointShadowArgs), _vp],
+    "vkr_gbuffer": [C.POINTER(GpassArgs), _vp],
+    "vkr_gbuffer_workspace_bytes": [_i32, _i32, _i32],
     "vkr_dir_shadow_map": [C.POINTER(DirShadowArgs), _vp],
     "vkr_bloom_blur": [C.POINTER(BloomArgs), _vp],
     "vkr_postprocess": [_vp, _vp, _vp, _i32, _i32, _i32, _vp],
@@ -161,6 +180,9 @@ PROTOTYPES = {
 _lib = None
 
 
+RETURNS_INT64 = {"vkr_gbuffer_workspace_bytes"}
+
+
 def load() -> C.CDLL:
     """Loads libvkr_hip.so once and sets the prototypes of every entry point in include/vkr_hip.h."""
     global _lib
@@ -174,7 +196,7 @@ def load() -> C.CDLL:
     lib.vkr_last_error.argtypes = []
     for name, argtypes in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
-        fn.restype = C.c_int32
+        fn.restype = C.c_int64 if name in RETURNS_INT64 else C.c_int32
         fn.argtypes = argtypes
     _lib = lib
     return lib

@@ -1,0 +1,259 @@
+// Geometry pass on gfx950: gpass.vert / gpass.frag over the frame's draw calls
+// (VulkanRenderer.cs:378-404), BACK faces culled, CCW front, depth test LESS, four RGBA16F
+// targets cleared to (0,0,0,0), (0,0,0,1), (0,0,0,1), (0,0,0,1) (VulkanRenderer.cs:1155-1161,
+// GraphicsPipeline.cs:71-73).
+//
+// Two kernels instead of a depth-tested raster pipeline:
+//  1. visibility -- one lane per triangle walks the pixels of its bounding box and takes
+//     atomicMin on a 64-bit key per pixel, depth bits (z/w as binary32) above the triangle's
+//     number in submission order: the minimum is the LESS winner, an earlier triangle winning a
+//     tie, whatever order lanes run in;
+//  2. resolve -- one lane per pixel re-runs the vertex shader for the three corners of the
+//     winner, interpolates its outputs perspective-correctly, samples the material and writes the
+//     four targets once.  Hidden fragments are never shaded and no target is read back.
+// Material textures are single-level RGBA8 images read through textureSampler (LINEAR, REPEAT;
+// the sampler's anisotropic filtering is implementation-defined and not modelled); albedo and
+// the ao/roughness/metalness image are _SRGB, the normal map _UNORM (Texture.cs:21).
+#include <math.h>
+#include <mutex>
+#include "vkr_device.h"
+#include "vkr_host.h"
+#include "vkr_raster.h"
+
+namespace vkr {
+
+__device__ float g_gp_srgb[256];  // sRGB 8-bit -> linear, from the host C library like the oracle's
+static std::mutex g_gp_mutex;
+static bool g_gp_ready[64];
+
+static int32_t ensure_srgb_table()
+{
+    int dev = 0;
+    VKR_HIP_CHECK(hipGetDevice(&dev));
+    VKR_REQUIRE(dev >= 0 && dev < 64, "device ordinal %d out of range", dev);
+    std::lock_guard<std::mutex> lock(g_gp_mutex);
+    if (g_gp_ready[dev]) return VKR_OK;
+    static float lut[256];
+    for (int i = 0; i < 256; i++) {
+        float c = (float)i * (1.0f / 255.0f);
+        lut[i] = c <= 0.04045f ? c * (1.0f / 12.92f) : powf((c + 0.055f) * (1.0f / 1.055f), 2.4f);
+    }
+    VKR_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_gp_srgb), lut, sizeof(lut)));
+    g_gp_ready[dev] = true;
+    return VKR_OK;
+}
+
+struct GpassParams {
+    const VkrGpassDraw *draws;  // device copy
+    int n_draws;
+    int draw;                   // visibility kernel: the draw of this launch
+    unsigned tri_base;          // number of its first triangle in submission order
+    float vp[16];               // (proj * view), row-vector convention
+    int width, rows, frame_rows, row0;
+    unsigned long long *vis;
+    uint2 *albedo, *normal, *arm, *position;
+};
+
+struct GpVertex { float pos[4], uv[2], tbn[9], clip[4]; };
+
+// gpass.vert:24-35
+VKR_DEV void gpass_vertex(const VkrGpassDraw &d, const float *vp, unsigned i, GpVertex &o, bool attributes)
+{
+    i = min(i, (unsigned)d.n_verts - 1u);  // an index past the arrays would fault
+    const float p4[4] = {d.positions[3 * i], d.positions[3 * i + 1], d.positions[3 * i + 2], 1.0f};
+    mat4_vec4(d.model, p4, o.pos);
+    mat4_vec4(vp, o.pos, o.clip);
+    if (!attributes) return;
+    o.uv[0] = d.texcoords[2 * i]; o.uv[1] = d.texcoords[2 * i + 1];
+    const float t4[4] = {d.tangents[3 * i], d.tangents[3 * i + 1], d.tangents[3 * i + 2], 0.0f};
+    const float n4[4] = {d.normals[3 * i], d.normals[3 * i + 1], d.normals[3 * i + 2], 0.0f};
+    float tw[4], nw[4];
+    mat4_vec4(d.model, t4, tw);
+    mat4_vec4(d.model, n4, nw);
+    f3 T = normalize3(mk3(tw[0], tw[1], tw[2]));
+    const f3 N = normalize3(mk3(nw[0], nw[1], nw[2]));
+    const float tn = dot3(T, N);
+    T = normalize3(mk3(T.x - tn * N.x, T.y - tn * N.y, T.z - tn * N.z));
+    const f3 B = cross3(N, T);
+    o.tbn[0] = T.x; o.tbn[1] = T.y; o.tbn[2] = T.z;
+    o.tbn[3] = B.x; o.tbn[4] = B.y; o.tbn[5] = B.z;
+    o.tbn[6] = N.x; o.tbn[7] = N.y; o.tbn[8] = N.z;
+}
+
+__global__ __launch_bounds__(256) void gpass_visibility_kernel(const GpassParams p)
+{
+    const VkrGpassDraw &d = p.draws[p.draw];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= d.n_tris) return;
+    float clip[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        GpVertex v;
+        gpass_vertex(d, p.vp, d.indices[3 * t + k], v, false);
+#pragma unroll
+        for (int j = 0; j < 4; j++) clip[k][j] = v.clip[j];
+    }
+    STri tr;
+    raster_setup(clip, tr);
+    if (!(tr.D < 0.0)) return;  // BACK faces (D > 0) and degenerate triangles are culled
+    raster_flip(tr);
+    int qx0, qy0, qx1, qy1, rx0, ry0, rx1, ry1;
+    if (!shadow_bbox(clip, p.width, qx0, qy0, qx1, qy1)) return;
+    if (!shadow_bbox(clip, p.frame_rows, rx0, ry0, rx1, ry1)) return;
+    const int by0 = max(ry0 - p.row0, 0), by1 = min(ry1 - p.row0, p.rows - 1);
+    const double sx = 2.0 / (double)p.width, sy = 2.0 / (double)p.frame_rows;
+    const unsigned long long id = (unsigned long long)(p.tri_base + (unsigned)t);
+    for (int y = by0; y <= by1; y++) {
+        const double yn = __builtin_fma((double)(p.row0 + y) + 0.5, sy, -1.0);
+        for (int x = qx0; x <= qx1; x++) {
+            const double xn = __builtin_fma((double)x + 0.5, sx, -1.0);
+            const double e0 = s_edge(tr, 0, xn, yn), e1 = s_edge(tr, 1, xn, yn), e2 = s_edge(tr, 2, xn, yn);
+            if (!(e0 >= 0.0 && e1 >= 0.0 && e2 >= 0.0 && (e0 + e1) + e2 > 0.0)) continue;
+            const double zs = __builtin_fma(e2, tr.z[2], __builtin_fma(e1, tr.z[1], e0 * tr.z[0]));
+            if (!(zs >= 0.0 && zs <= tr.D)) continue;
+            const float depth = (float)(zs / tr.D) + 0.0f;
+            const unsigned long long key = ((unsigned long long)__builtin_bit_cast(unsigned int, depth) << 32) | id;
+            atomicMin(p.vis + (size_t)y * p.width + x, key);
+        }
+    }
+}
+
+// textureSampler on a single-level RGBA8 image: LINEAR, REPEAT; srgb: r, g, b are decoded before filtering
+VKR_DEV void tex2d_rgba8(const VkrTexture &t, bool srgb, float s, float tt, float (&o)[4])
+{
+    const int w = t.width, h = t.height;
+    const float x = s * (float)w - 0.5f, y = tt * (float)h - 0.5f;
+    const float fx = __builtin_floorf(x), fy = __builtin_floorf(y);
+    const float al = x - fx, be = y - fy;
+    const int i0 = wrap_repeat((int)fx, w), i1 = wrap_repeat((int)fx + 1, w);
+    const int j0 = wrap_repeat((int)fy, h), j1 = wrap_repeat((int)fy + 1, h);
+    const float w00 = (1.0f - al) * (1.0f - be), w10 = al * (1.0f - be), w01 = (1.0f - al) * be, w11 = al * be;
+    const uint32_t *img = (const uint32_t *)t.rgba8;
+    const uint32_t p00 = img[(size_t)j0 * w + i0], p10 = img[(size_t)j0 * w + i1], p01 = img[(size_t)j1 * w + i0], p11 = img[(size_t)j1 * w + i1];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const uint32_t b00 = (p00 >> (8 * c)) & 0xFF, b10 = (p10 >> (8 * c)) & 0xFF, b01 = (p01 >> (8 * c)) & 0xFF, b11 = (p11 >> (8 * c)) & 0xFF;
+        float a, b, cc, d;
+        if (srgb && c < 3) { a = g_gp_srgb[b00]; b = g_gp_srgb[b10]; cc = g_gp_srgb[b01]; d = g_gp_srgb[b11]; }
+        else { a = (float)b00 * (1.0f / 255.0f); b = (float)b10 * (1.0f / 255.0f); cc = (float)b01 * (1.0f / 255.0f); d = (float)b11 * (1.0f / 255.0f); }
+        o[c] = fma_(w11, d, fma_(w01, cc, fma_(w10, b, w00 * a)));
+    }
+}
+
+__global__ __launch_bounds__(256) void gpass_resolve_kernel(const GpassParams p)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= p.width || y >= p.rows) return;
+    const size_t px = (size_t)y * p.width + x;
+    const unsigned long long key = p.vis[px];
+    if (key == ~0ull) {  // clear values
+        p.albedo[px] = make_uint2(0u, 0u);
+        const uint2 zero_one = pack4(0.0f, 0.0f, 0.0f, 1.0f);
+        p.normal[px] = zero_one; p.arm[px] = zero_one; p.position[px] = zero_one;
+        return;
+    }
+    unsigned id = (unsigned)(key & 0xFFFFFFFFull), base = 0;
+    int di = 0;
+    while (di + 1 < p.n_draws && id - base >= (unsigned)p.draws[di].n_tris) { base += (unsigned)p.draws[di].n_tris; di++; }
+    const VkrGpassDraw &d = p.draws[di];
+    const unsigned t = id - base;
+    GpVertex v[3];
+    float clip[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        gpass_vertex(d, p.vp, d.indices[3 * t + k], v[k], true);
+#pragma unroll
+        for (int j = 0; j < 4; j++) clip[k][j] = v[k].clip[j];
+    }
+    STri tr;
+    raster_setup(clip, tr);
+    raster_flip(tr);
+    const double sx = 2.0 / (double)p.width, sy = 2.0 / (double)p.frame_rows;
+    const double xn = __builtin_fma((double)x + 0.5, sx, -1.0), yn = __builtin_fma((double)(p.row0 + y) + 0.5, sy, -1.0);
+    const double e0 = s_edge(tr, 0, xn, yn), e1 = s_edge(tr, 1, xn, yn), e2 = s_edge(tr, 2, xn, yn);
+    const double s = (e0 + e1) + e2;
+    auto lerp = [&](float a0, float a1, float a2) { return (float)(__builtin_fma(e2, (double)a2, __builtin_fma(e1, (double)a1, e0 * (double)a0)) / s); };
+    const float u = lerp(v[0].uv[0], v[1].uv[0], v[2].uv[0]), vv = lerp(v[0].uv[1], v[1].uv[1], v[2].uv[1]);
+    float pos[4], tbn[9];
+#pragma unroll
+    for (int k = 0; k < 4; k++) pos[k] = lerp(v[0].pos[k], v[1].pos[k], v[2].pos[k]);
+#pragma unroll
+    for (int k = 0; k < 9; k++) tbn[k] = lerp(v[0].tbn[k], v[1].tbn[k], v[2].tbn[k]);
+    // gpass.frag:18-28
+    float alb[4], nm[4], arm[4];
+    tex2d_rgba8(d.albedo, true, u, vv, alb);
+    tex2d_rgba8(d.normal, false, u, vv, nm);
+    tex2d_rgba8(d.arm, true, u, vv, arm);
+    const f3 n = normalize3(mk3(fma_(nm[0], 2.0f, -1.0f), fma_(nm[1], 2.0f, -1.0f), fma_(nm[2], 2.0f, -1.0f)));
+    const float wn0 = fma_(tbn[6], n.z, fma_(tbn[3], n.y, tbn[0] * n.x));
+    const float wn1 = fma_(tbn[7], n.z, fma_(tbn[4], n.y, tbn[1] * n.x));
+    const float wn2 = fma_(tbn[8], n.z, fma_(tbn[5], n.y, tbn[2] * n.x));
+    p.albedo[px] = pack4(alb[0], alb[1], alb[2], alb[3]);
+    p.normal[px] = pack4(wn0, wn1, wn2, 1.0f);
+    p.arm[px] = pack4(arm[0], arm[1], arm[2], arm[3]);
+    p.position[px] = pack4(pos[0], pos[1], pos[2], pos[3]);
+}
+
+__global__ __launch_bounds__(256) void fill_u64_kernel(unsigned long long *out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = ~0ull;
+}
+
+}  // namespace vkr
+
+extern "C" int64_t vkr_gbuffer_workspace_bytes(int32_t width, int32_t rows, int32_t n_draws)
+{
+    if (width <= 0 || rows <= 0 || n_draws < 0) return -1;
+    return (int64_t)width * rows * 8 + (int64_t)n_draws * (int64_t)sizeof(VkrGpassDraw) + 256;
+}
+
+extern "C" int32_t vkr_gbuffer(const VkrGpassArgs *a, void *stream)
+{
+    using namespace vkr;
+    VKR_REQUIRE(a != nullptr, "vkr_gbuffer: args is null");
+    VKR_REQUIRE(a->width > 0 && a->rows > 0, "vkr_gbuffer: bad size %dx%d", a->width, a->rows);
+    VKR_REQUIRE(a->frame_rows >= a->rows && a->row0 >= 0 && a->row0 + a->rows <= a->frame_rows, "vkr_gbuffer: rows [%d,%d) outside a frame of %d rows", a->row0, a->row0 + a->rows, a->frame_rows);
+    VKR_REQUIRE(a->n_draws >= 0 && (a->n_draws == 0 || a->draws), "vkr_gbuffer: draws missing");
+    VKR_REQUIRE(a->albedo && a->normal && a->arm && a->position, "vkr_gbuffer: an output image is null");
+    uint64_t total_tris = 0;
+    for (int d = 0; d < a->n_draws; d++) {
+        const VkrGpassDraw &g = a->draws[d];
+        VKR_REQUIRE(g.positions && g.texcoords && g.normals && g.tangents && g.indices && g.n_verts > 0 && g.n_tris >= 0, "vkr_gbuffer: draw %d has no mesh", d);
+        const VkrTexture *tex[3] = {&g.albedo, &g.normal, &g.arm};
+        for (const VkrTexture *t : tex) VKR_REQUIRE(t->rgba8 && t->width > 0 && t->height > 0, "vkr_gbuffer: draw %d lacks a material image", d);
+        total_tris += (uint64_t)g.n_tris;
+    }
+    VKR_REQUIRE(total_tris < (1ull << 32) - 1, "vkr_gbuffer: too many triangles");
+    const int64_t need = vkr_gbuffer_workspace_bytes(a->width, a->rows, a->n_draws);
+    VKR_REQUIRE(a->workspace && a->workspace_bytes >= need, "vkr_gbuffer: workspace of %lld bytes needed (vkr_gbuffer_workspace_bytes)", (long long)need);
+    int32_t rc = ensure_srgb_table();
+    if (rc != VKR_OK) return rc;
+
+    GpassParams p;
+    const size_t npx = (size_t)a->width * a->rows;
+    p.vis = (unsigned long long *)a->workspace;
+    VkrGpassDraw *dev_draws = (VkrGpassDraw *)((char *)a->workspace + ((npx * 8 + 255) & ~(size_t)255));
+    p.draws = dev_draws; p.n_draws = a->n_draws;
+    if (a->n_draws) VKR_HIP_CHECK(hipMemcpyAsync(dev_draws, a->draws, (size_t)a->n_draws * sizeof(VkrGpassDraw), hipMemcpyHostToDevice, as_stream(stream)));
+    // (proj * view), as gpass.vert:26 associates it
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            const float *v = a->scene.camera_view, *q = a->scene.camera_projection;
+            p.vp[4 * i + j] = fmaf(v[4 * i + 3], q[12 + j], fmaf(v[4 * i + 2], q[8 + j], fmaf(v[4 * i + 1], q[4 + j], v[4 * i] * q[j])));
+        }
+    p.width = a->width; p.rows = a->rows; p.frame_rows = a->frame_rows; p.row0 = a->row0;
+    p.albedo = (uint2 *)a->albedo; p.normal = (uint2 *)a->normal; p.arm = (uint2 *)a->arm; p.position = (uint2 *)a->position;
+    p.draw = 0; p.tri_base = 0;
+    hipLaunchKernelGGL(fill_u64_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, as_stream(stream), p.vis, npx);
+    unsigned base = 0;
+    for (int d = 0; d < a->n_draws; d++) {
+        if (a->draws[d].n_tris > 0) {
+            p.draw = d; p.tri_base = base;
+            hipLaunchKernelGGL(gpass_visibility_kernel, dim3((unsigned)((a->draws[d].n_tris + 255) / 256)), dim3(256), 0, as_stream(stream), p);
+        }
+        base += (unsigned)a->draws[d].n_tris;
+    }
+    hipLaunchKernelGGL(gpass_resolve_kernel, dim3((unsigned)((a->width + 63) / 64), (unsigned)((a->rows + 3) / 4)), dim3(256), 0, as_stream(stream), p);
+    return launch_status("vkr_gbuffer");
+}

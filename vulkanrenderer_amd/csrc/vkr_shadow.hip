@@ -15,6 +15,7 @@
 // 8x4-texel tiles, the layout the shading kernel gathers from fastest.
 #include "vkr_device.h"
 #include "vkr_host.h"
+#include "vkr_raster.h"
 
 namespace vkr {
 
@@ -26,23 +27,6 @@ struct ShadowParams {
     int res; float far_plane; int tiled;
     float *out;
 };
-
-struct STri { double a[3], b[3], c[3], z[3], D; };
-
-VKR_DEV double s_edge(const STri &t, int i, double xn, double yn) { return __builtin_fma(t.a[i], xn, __builtin_fma(t.b[i], yn, t.c[i])); }
-
-// row-major 4x4 product in the row-vector convention, each element one fma chain
-VKR_DEV float mat4_mul_elem(const float *a, const float *b, int i, int j)
-{
-    return fma_(a[4 * i + 3], b[12 + j], fma_(a[4 * i + 2], b[8 + j], fma_(a[4 * i + 1], b[4 + j], a[4 * i] * b[j])));
-}
-
-// GLSL mat4 * vec4 on row-major bytes: out[j] = sum_i v[i] * m[4i + j]
-VKR_DEV void mat4_vec4(const float *m, const float (&v)[4], float (&o)[4])
-{
-#pragma unroll
-    for (int j = 0; j < 4; j++) o[j] = fma_(v[3], m[12 + j], fma_(v[2], m[8 + j], fma_(v[1], m[4 + j], v[0] * m[j])));
-}
 
 // CreateLookAt(eye, eye + dir, up) * CreatePerspectiveFieldOfView(pi/2, 1, 1, far), VulkanRenderer.cs:327-339.
 // The look-at axes are exact signed unit vectors; 1/tan(pi/4) is taken as exactly 1.
@@ -64,45 +48,6 @@ VKR_DEV void shadow_face_matrix_elem(const float *eye, int face, float far_plane
     out16[idx] = mat4_mul_elem(view, proj, idx >> 2, idx & 3);
 }
 
-// Conservative texel bounding box of the part of a clip-space triangle with z >= 0 and w > 0.
-VKR_DEV bool shadow_bbox(const float (&c)[3][4], int res, int &bx0, int &by0, int &bx1, int &by1)
-{
-    double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
-    int n = 0;
-    bool unbounded = false;
-    auto add = [&](double x, double y, double w) {
-        n++;
-        if (!(w > 1e-12)) { unbounded = true; return; }
-        const double px = x / w, py = y / w;
-        xmin = px < xmin ? px : xmin; xmax = px > xmax ? px : xmax;
-        ymin = py < ymin ? py : ymin; ymax = py > ymax ? py : ymax;
-    };
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const float *a = c[i], *b = c[(i + 1) % 3];
-        const bool ain = a[2] >= 0.0f && a[3] > 0.0f, bin = b[2] >= 0.0f && b[3] > 0.0f;
-        if (ain) add(a[0], a[1], a[3]);
-        if (ain != bin) {
-            const double ta = a[2], tb = b[2];
-            double t = (ta != tb) ? ta / (ta - tb) : 0.5;
-            if (!(t >= 0.0 && t <= 1.0)) { const double wa = a[3], wb = b[3]; t = (wa != wb) ? wa / (wa - wb) : 0.5; }
-            add((double)a[0] + t * ((double)b[0] - (double)a[0]), (double)a[1] + t * ((double)b[1] - (double)a[1]), (double)a[3] + t * ((double)b[3] - (double)a[3]));
-        }
-    }
-    if (n == 0) return false;
-    if (unbounded) { xmin = ymin = -1e300; xmax = ymax = 1e300; }
-    const double half = 0.5 * (double)res;
-    double fx0 = __builtin_floor((xmin + 1.0) * half - 0.5) - 1.0, fx1 = __builtin_ceil((xmax + 1.0) * half - 0.5) + 1.0;
-    double fy0 = __builtin_floor((ymin + 1.0) * half - 0.5) - 1.0, fy1 = __builtin_ceil((ymax + 1.0) * half - 0.5) + 1.0;
-    if (!(fx0 > 0.0)) fx0 = 0.0;
-    if (!(fy0 > 0.0)) fy0 = 0.0;
-    if (!(fx1 < (double)(res - 1))) fx1 = (double)(res - 1);
-    if (!(fy1 < (double)(res - 1))) fy1 = (double)(res - 1);
-    if (fx0 > fx1 || fy0 > fy1) return false;
-    bx0 = (int)fx0; by0 = (int)fy0; bx1 = (int)fx1; by1 = (int)fy1;
-    return true;
-}
-
 VKR_DEV size_t depth_texel_index(int res, int i, int j, bool tiled)
 {
     if (!tiled) return (size_t)j * res + i;
@@ -112,13 +57,8 @@ VKR_DEV size_t depth_texel_index(int res, int i, int j, bool tiled)
 // One triangle into one res x res depth image; world = corners' world positions (point lights) or null.
 VKR_DEV void shadow_raster(const float (&clip)[3][4], const float (*world)[4], const float *light_pos, float inv_far, int res, bool tiled, float *img)
 {
-    const double x0 = clip[0][0], y0 = clip[0][1], w0 = clip[0][3], x1 = clip[1][0], y1 = clip[1][1], w1 = clip[1][3], x2 = clip[2][0], y2 = clip[2][1], w2 = clip[2][3];
     STri t;
-    t.a[0] = y1 * w2 - w1 * y2; t.b[0] = w1 * x2 - x1 * w2; t.c[0] = x1 * y2 - y1 * x2;
-    t.a[1] = y2 * w0 - w2 * y0; t.b[1] = w2 * x0 - x2 * w0; t.c[1] = x2 * y0 - y2 * x0;
-    t.a[2] = y0 * w1 - w0 * y1; t.b[2] = w0 * x1 - x0 * w1; t.c[2] = x0 * y1 - y0 * x1;
-    t.z[0] = clip[0][2]; t.z[1] = clip[1][2]; t.z[2] = clip[2][2];
-    t.D = __builtin_fma(w0, t.c[0], __builtin_fma(y0, t.b[0], x0 * t.a[0]));
+    raster_setup(clip, t);
     if (!(t.D > 0.0)) return;  // front faces and degenerate triangles are culled
     int bx0, by0, bx1, by1;
     if (!shadow_bbox(clip, res, bx0, by0, bx1, by1)) return;

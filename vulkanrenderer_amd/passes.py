@@ -143,6 +143,39 @@ def dir_shadow_map(draws, light_space, res: int, device) -> torch.Tensor:
     return out
 
 
+def gbuffer(draws, scene: np.ndarray, width: int, rows: int, device, frame_rows: int | None = None, row0: int = 0):
+    """The geometry pass: (albedo, normal, arm, position) float16 [rows, width, 4].  draws: list of dicts of
+    device tensors -- positions [n,3], texcoords [n,2], normals [n,3], tangents [n,3] float32, triangles [m,3]
+    int32, the RGBA8 images albedo / normal / arm [h,w,4] uint8 -- and `model` (16 floats)."""
+    lib = _lib.load()
+    arr = (_lib.GpassDraw * len(draws))()
+    for k, d in enumerate(draws):
+        for name in ("positions", "texcoords", "normals", "tangents"):
+            t = d[name]
+            assert t.dtype == torch.float32 and t.is_contiguous()
+            setattr(arr[k], name, t.data_ptr())
+        tri = d["triangles"]
+        assert tri.dtype == torch.int32 and tri.is_contiguous()
+        arr[k].n_verts, arr[k].indices, arr[k].n_tris = d["positions"].shape[0], tri.data_ptr(), tri.shape[0]
+        arr[k].model[:] = [float(v) for v in np.asarray(d["model"], dtype=np.float32).ravel()]
+        for name in ("albedo", "normal", "arm"):
+            t = d[name]
+            assert t.dtype == torch.uint8 and t.is_contiguous() and t.shape[-1] == 4
+            tex = getattr(arr[k], name)
+            tex.rgba8, tex.width, tex.height = t.data_ptr(), t.shape[1], t.shape[0]
+    out = [torch.empty((rows, width, 4), dtype=torch.float16, device=device) for _ in range(4)]
+    need = lib.vkr_gbuffer_workspace_bytes(width, rows, len(draws))
+    workspace = torch.empty(need, dtype=torch.uint8, device=device)
+    a = _lib.GpassArgs()
+    a.draws, a.n_draws = arr, len(draws)
+    a.scene = _scene_struct(scene)
+    a.width, a.rows, a.frame_rows, a.row0 = width, rows, rows if frame_rows is None else frame_rows, row0
+    a.albedo, a.normal, a.arm, a.position = (_ptr(o) for o in out)
+    a.workspace, a.workspace_bytes = _ptr(workspace), need
+    _lib.check(lib.vkr_gbuffer(C.byref(a), _stream()))
+    return tuple(out)
+
+
 def tile_depth_cubes(linear: torch.Tensor) -> torch.Tensor:
     """[..., res, res] float32 depth faces, row-major -> the same faces as 8x4-texel tiles (new tensor)."""
     lib = _lib.load()

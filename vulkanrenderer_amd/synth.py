@@ -152,6 +152,35 @@ def make_scene_mesh(n: int = 64, thickness: float = 0.3, extent: float = 3.0):
     return verts, t
 
 
+def mesh_attributes(verts: np.ndarray, tris: np.ndarray, uv_scale: float = 1.0):
+    """Per-vertex normals (area-weighted), planar texture coordinates and tangents for a mesh: what gpass.vert
+    reads beside the position (Mesh.cs vertex layout: position, texcoord, normal, tangent)."""
+    v = verts.astype(np.float64)
+    fn = np.cross(v[tris[:, 1]] - v[tris[:, 0]], v[tris[:, 2]] - v[tris[:, 0]])
+    n = np.zeros_like(v)
+    for k in range(3):
+        np.add.at(n, tris[:, k], fn)
+    n /= np.maximum(np.linalg.norm(n, axis=1, keepdims=True), 1e-20)
+    uv = np.stack([v[:, 0], v[:, 2]], -1) * uv_scale + 0.5 * v[:, 1:2]
+    t = np.cross(np.array([0.0, 0.0, 1.0]), n)
+    small = np.linalg.norm(t, axis=1) < 1e-3
+    t[small] = np.cross(np.array([1.0, 0.0, 0.0]), n[small])
+    t /= np.linalg.norm(t, axis=1, keepdims=True)
+    return uv.astype(np.float32), n.astype(np.float32), t.astype(np.float32)
+
+
+def make_material(rng: np.random.Generator, size: int = 64):
+    """Three RGBA8 images (albedo, normal map, ao/roughness/metalness) with smooth content."""
+    f = _smooth_field(rng, size, 6, 9)
+    albedo = np.concatenate([0.1 + 0.8 * f[0:3], np.ones((1, size, size))]).transpose(1, 2, 0)
+    tilt = 0.35 * (f[3:5] - 0.5)
+    nz = np.sqrt(np.maximum(1.0 - (tilt ** 2).sum(0), 0.0))
+    normal = np.concatenate([0.5 + 0.5 * tilt, (0.5 + 0.5 * nz)[None], np.ones((1, size, size))]).transpose(1, 2, 0)
+    arm = np.concatenate([0.6 + 0.4 * f[5:6], 0.2 + 0.7 * f[6:7], f[7:8], np.ones((1, size, size))]).transpose(1, 2, 0)
+    q = lambda a: np.ascontiguousarray(np.clip(np.rint(a * 255.0), 0, 255).astype(np.uint8))
+    return q(albedo), q(normal), q(arm)
+
+
 def default_scene_info() -> np.ndarray:
     """SceneInfo of the reference's demo frame (Program.cs:84,120-132)."""
     s = np.zeros((), dtype=SCENE_DTYPE)
