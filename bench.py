@@ -161,7 +161,7 @@ def time_coverage(f, dev_frame, renderer, device) -> dict:
 
 
 def time_shadow_pass(f, dev_frame, device) -> dict:
-    """The passes that make the shadow maps (VulkanRenderer.cs:325-376, 406-428), on the synthetic scene's
+    """The passes that make the shadow maps and the G-buffer (VulkanRenderer.cs:325-428), on the synthetic scene's
     mesh: a closed slab under the height field, 129^2 grid.  Not part of a step (the benchmark frame keeps its
     synthetic maps resident); what a frame with moving lights would add."""
     import torch
@@ -179,8 +179,18 @@ def time_shadow_pass(f, dev_frame, device) -> dict:
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
 
+    uv, nrm, tan = synth.mesh_attributes(verts, tris, uv_scale=0.25)
+    alb, nmap, arm = synth.make_material(np.random.default_rng(SEED + 9), 1024)
+    dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(device)
+    gdraws = [dict(positions=draws[0][0], triangles=draws[0][1], texcoords=dev(uv, np.float32), normals=dev(nrm, np.float32),
+                   tangents=dev(tan, np.float32), albedo=dev(alb, np.uint8), normal=dev(nmap, np.uint8), arm=dev(arm, np.uint8), model=np.eye(4))]
+    scene = f.scene.copy()
+    scene["camera_projection"] = synth.perspective(60.0, f.width / f.height, 0.1, 100.0).astype(np.float32).ravel()
+    ga = P.gbuffer(gdraws, scene, f.width, f.height, device)[0]
     return {"point_shadow_ms": round(timed(lambda: P.point_shadow_maps(draws, dev_frame.lights, nl, res)), 4),
             "dir_shadow_ms": round(timed(lambda: P.dir_shadow_map(draws, f.scene["light_space_matrix"], dres, device)), 4),
+            "geometry_pass_ms": round(timed(lambda: P.gbuffer(gdraws, scene, f.width, f.height, device)), 4),
+            "geometry_pass_covered_fraction": round(float((ga[..., 3] != 0).float().mean()), 4),
             "config": f"{nl} lights x 6 x {res}^2 D32F (written as 8x4 tiles) + {dres}^2 directional map; mesh {len(verts)} vertices, {len(tris)} triangles"}
 
 

@@ -32,7 +32,9 @@ internal static unsafe class Native
     [DllImport(Lib)] public static extern int vkr_set_lights(nint ctx, LightInfo* lights, int n, int coverageMode);
     [DllImport(Lib)] public static extern int vkr_set_light_volume_mesh(nint ctx, float* verts, int nVerts, uint* indices, int nTris);
     [DllImport(Lib)] public static extern int vkr_create_mesh(nint ctx, float* positions, int nVerts, uint* indices, int nTris, out int mesh);
-    [DllImport(Lib)] public static extern int vkr_draw_model(nint ctx, int mesh, in Matrix4X4<float> model);
+    [DllImport(Lib)] public static extern int vkr_set_mesh_attributes(nint ctx, int mesh, float* texcoords, float* normals, float* tangents);
+    [DllImport(Lib)] public static extern int vkr_create_material(nint ctx, void* albedo, int aw, int ah, void* normal, int nw, int nh, void* arm, int mw, int mh, out int material);
+    [DllImport(Lib)] public static extern int vkr_draw_model(nint ctx, int mesh, int material, in Matrix4X4<float> model);
     [DllImport(Lib)] public static extern int vkr_begin_frame(nint ctx);
     [DllImport(Lib)] public static extern int vkr_end_frame(nint ctx);
     [DllImport(Lib)] public static extern int vkr_upload_gbuffer(nint ctx, void* albedo, void* normal, void* arm, void* position);
@@ -80,7 +82,13 @@ public sealed unsafe class HipRenderer : IDisposable
         Check(Native.vkr_create_mesh(ctx, positions, nVerts, indices, nTris, out int mesh));
         return mesh;
     }
-    public void DrawModel(int mesh, Matrix4X4<float> modelMatrix) => Check(Native.vkr_draw_model(ctx, mesh, modelMatrix));
+    public void SetMeshAttributes(int mesh, float* texcoords, float* normals, float* tangents) => Check(Native.vkr_set_mesh_attributes(ctx, mesh, texcoords, normals, tangents));
+    public int CreateMaterial(void* albedo, int aw, int ah, void* normal, int nw, int nh, void* arm, int mw, int mh)
+    {
+        Check(Native.vkr_create_material(ctx, albedo, aw, ah, normal, nw, nh, arm, mw, mh, out int material));
+        return material;
+    }
+    public void DrawModel(int mesh, int material, Matrix4X4<float> modelMatrix) => Check(Native.vkr_draw_model(ctx, mesh, material, modelMatrix));
 
     // sphereMesh of the reference (VulkanRenderer.cs:78,269): positions and indices of the light volume
     public void SetLightVolumeMesh(float* verts, int nVerts, uint* indices, int nTris)

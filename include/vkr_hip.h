@@ -309,14 +309,21 @@ VKR_EXPORT int32_t vkr_begin_frame(vkr_ctx *ctx);                               
 VKR_EXPORT int32_t vkr_end_frame(vkr_ctx *ctx);
 VKR_EXPORT int32_t vkr_current_frame(vkr_ctx *ctx);
 
-/* Meshes and the frame's draw calls.  vkr_create_mesh keeps a mesh on the device (Mesh.cs); vkr_draw_model is
- * DrawModel (VulkanRenderer.cs:630-633): it queues the mesh with a model matrix between BeginFrame and EndFrame.
- * When a frame has draw calls, EndFrame renders the point-light depth cubes and the directional depth map from
- * them (VulkanRenderer.cs:325-376, 406-428) before the composition pass; otherwise uploaded maps are used. */
+/* Meshes, materials and the frame's draw calls (Mesh.cs, Material.cs, Model.cs).  vkr_draw_model is DrawModel
+ * (VulkanRenderer.cs:630-633): it queues a mesh with a material and a model matrix between BeginFrame and
+ * EndFrame.  With draw calls in a frame, EndFrame renders the point-light depth cubes and the directional depth
+ * map from them (VulkanRenderer.cs:325-376, 406-428); if every draw has a material (material >= 0) and its mesh
+ * has attributes, it also renders the G-buffer (VulkanRenderer.cs:378-404).  What is not rendered is taken from
+ * the vkr_upload_* calls. */
 VKR_EXPORT int32_t vkr_create_mesh(vkr_ctx *ctx, const float *positions, int32_t n_verts, const uint32_t *indices, int32_t n_tris, int32_t *mesh_out);
-VKR_EXPORT int32_t vkr_draw_model(vkr_ctx *ctx, int32_t mesh, const float *model16);
+VKR_EXPORT int32_t vkr_set_mesh_attributes(vkr_ctx *ctx, int32_t mesh, const float *texcoords, const float *normals, const float *tangents);
+/* Three single-level RGBA8 images: albedo (_SRGB), normal map (_UNORM), ao/roughness/metalness (_SRGB). */
+VKR_EXPORT int32_t vkr_create_material(vkr_ctx *ctx, const void *albedo, int32_t albedo_w, int32_t albedo_h,
+                                       const void *normal, int32_t normal_w, int32_t normal_h,
+                                       const void *arm, int32_t arm_w, int32_t arm_h, int32_t *material_out);
+VKR_EXPORT int32_t vkr_draw_model(vkr_ctx *ctx, int32_t mesh, int32_t material, const float *model16);
 
-/* Inputs the out-of-scope geometry pass (and, without draw calls, the shadow passes) would have produced for the current frame. */
+/* Images of passes the frame does not render itself (see vkr_draw_model), for the current frame. */
 VKR_EXPORT int32_t vkr_upload_gbuffer(vkr_ctx *ctx, const void *albedo, const void *normal, const void *arm, const void *position);
 VKR_EXPORT int32_t vkr_upload_background(vkr_ctx *ctx, const void *rgba16f_or_null);
 VKR_EXPORT int32_t vkr_upload_dir_shadow(vkr_ctx *ctx, const float *depth);

@@ -89,7 +89,18 @@ public:
         check(vkr_create_mesh(ctx_, positions, n_verts, indices, n_tris, &mesh));
         return mesh;
     }
-    void DrawModel(int32_t mesh, const float (&model_matrix)[16]) { check(vkr_draw_model(ctx_, mesh, model_matrix)); }
+    void SetMeshAttributes(int32_t mesh, const float *texcoords, const float *normals, const float *tangents)
+    {
+        check(vkr_set_mesh_attributes(ctx_, mesh, texcoords, normals, tangents));
+    }
+    int32_t CreateMaterial(const void *albedo, int32_t aw, int32_t ah, const void *normal, int32_t nw, int32_t nh, const void *arm, int32_t mw, int32_t mh)
+    {
+        int32_t material = -1;
+        check(vkr_create_material(ctx_, albedo, aw, ah, normal, nw, nh, arm, mw, mh, &material));
+        return material;
+    }
+    // material -1: the draw casts shadows only and the G-buffer comes from UploadGBuffer
+    void DrawModel(int32_t mesh, const float (&model_matrix)[16], int32_t material = -1) { check(vkr_draw_model(ctx_, mesh, material, model_matrix)); }
     // The reference's sphereMesh (VulkanRenderer.cs:78,269): once set, each light's draw touches only the
     // pixels its volume covers, as the reference's rasterised volumes do.
     void SetLightVolumeMesh(const float *verts, int32_t n_verts, const uint32_t *indices, int32_t n_tris)

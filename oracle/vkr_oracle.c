@@ -1306,6 +1306,35 @@ static void tex2d_rgba8_linear_repeat(const orc_texture *t, int srgb, float s, f
     }
 }
 
+/* gpass.frag:18-28 */
+static void gpass_fragment(const orc_gpass_draw *d, float u, float vv, const float *tbn, float *alb, float *wn, float *arm)
+{
+    float nm[4];
+    tex2d_rgba8_linear_repeat(&d->albedo, 1, u, vv, alb);
+    tex2d_rgba8_linear_repeat(&d->normal, 0, u, vv, nm);
+    tex2d_rgba8_linear_repeat(&d->arm, 1, u, vv, arm);
+    const v3 n = normalize3(v3_(fmaf(nm[0], 2.0f, -1.0f), fmaf(nm[1], 2.0f, -1.0f), fmaf(nm[2], 2.0f, -1.0f)));
+    /* mat3(T, B, N) * n */
+    wn[0] = fmaf(tbn[6], n.z, fmaf(tbn[3], n.y, tbn[0] * n.x));
+    wn[1] = fmaf(tbn[7], n.z, fmaf(tbn[4], n.y, tbn[1] * n.x));
+    wn[2] = fmaf(tbn[8], n.z, fmaf(tbn[5], n.y, tbn[2] * n.x));
+}
+
+/* probes for the golden vectors recorded from gpass.vert.spv / gpass.frag.spv */
+ORC_API void orc_gpass_vertex(const orc_scene_info *scene, const orc_gpass_draw *d, uint32_t i, float *pos4, float *clip4, float *tbn9)
+{
+    float vp[16];
+    gp_vertex o;
+    mat4_mul(scene->camera_view, scene->camera_proj, vp);
+    gpass_vertex(d, vp, i, &o);
+    memcpy(pos4, o.pos, 16); memcpy(clip4, o.clip, 16); memcpy(tbn9, o.tbn, 36);
+}
+ORC_API void orc_gpass_fragment(const orc_gpass_draw *d, float u, float v, const float *tbn9, float *alb4, float *wn3, float *arm4)
+{
+    build_srgb_lut();
+    gpass_fragment(d, u, v, tbn9, alb4, wn3, arm4);
+}
+
 ORC_API void orc_gbuffer(const orc_gpass_args *a)
 {
     build_srgb_lut();
@@ -1389,15 +1418,8 @@ ORC_API void orc_gbuffer(const orc_gpass_args *a)
             for (int k = 0; k < 4; k++) pos[k] = GP_LERP(pos, k);
             for (int k = 0; k < 9; k++) tbn[k] = GP_LERP(tbn, k);
 #undef GP_LERP
-            float alb[4], nm[4], arm[4];
-            tex2d_rgba8_linear_repeat(&d->albedo, 1, u, vv, alb);
-            tex2d_rgba8_linear_repeat(&d->normal, 0, u, vv, nm);
-            tex2d_rgba8_linear_repeat(&d->arm, 1, u, vv, arm);
-            const v3 n = normalize3(v3_(fmaf(nm[0], 2.0f, -1.0f), fmaf(nm[1], 2.0f, -1.0f), fmaf(nm[2], 2.0f, -1.0f)));
-            /* mat3(T, B, N) * n */
-            const float wn[3] = {fmaf(tbn[6], n.z, fmaf(tbn[3], n.y, tbn[0] * n.x)),
-                                 fmaf(tbn[7], n.z, fmaf(tbn[4], n.y, tbn[1] * n.x)),
-                                 fmaf(tbn[8], n.z, fmaf(tbn[5], n.y, tbn[2] * n.x))};
+            float alb[4], arm[4], wn[3];
+            gpass_fragment(d, u, vv, tbn, alb, wn, arm);
             for (int k = 0; k < 4; k++) { oa[k] = f2h(alb[k]); om[k] = f2h(arm[k]); op[k] = f2h(pos[k]); }
             for (int k = 0; k < 3; k++) on[k] = f2h(wn[k]);
             on[3] = 0x3C00;

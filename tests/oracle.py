@@ -225,6 +225,40 @@ def gbuffer(draws, scene: np.ndarray, width: int, rows: int, frame_rows: int | N
     return tuple(out)
 
 
+def _one_gpass_draw(d):
+    arr = (GpassDraw * 1)()
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    keep = [f32(d["positions"]), f32(d["texcoords"]), f32(d["normals"]), f32(d["tangents"])]
+    arr[0].positions, arr[0].texcoords, arr[0].normals, arr[0].tangents = (x.ctypes.data for x in keep)
+    arr[0].n_verts = len(keep[0])
+    arr[0].model[:] = [float(v) for v in np.asarray(d["model"], dtype=np.float32).ravel()]
+    for field in ("albedo", "normal", "arm"):
+        if field in d:
+            t = np.ascontiguousarray(d[field], dtype=np.uint8)
+            keep.append(t)
+            getattr(arr[0], field).rgba8 = t.ctypes.data
+            getattr(arr[0], field).width, getattr(arr[0], field).height = t.shape[1], t.shape[0]
+    return arr, keep
+
+
+def gpass_vertex(scene: np.ndarray, d: dict, i: int):
+    """gpass.vert for vertex i of a draw: (outPosition [4], gl_Position [4], TBN columns T,B,N [9])."""
+    arr, keep = _one_gpass_draw(d)
+    scene = np.ascontiguousarray(scene).reshape(1)
+    pos, clip, tbn = np.empty(4, np.float32), np.empty(4, np.float32), np.empty(9, np.float32)
+    load().orc_gpass_vertex(_p(scene), C.byref(arr[0]), C.c_uint32(i), _p(pos), _p(clip), _p(tbn))
+    return pos, clip, tbn
+
+
+def gpass_fragment(d: dict, uv, tbn):
+    """gpass.frag for one fragment: (albedo [4], world normal [3], arm [4]) before the binary16 store."""
+    arr, keep = _one_gpass_draw(d)
+    tbn = np.ascontiguousarray(tbn, dtype=np.float32)
+    alb, wn, arm = np.empty(4, np.float32), np.empty(3, np.float32), np.empty(4, np.float32)
+    load().orc_gpass_fragment(C.byref(arr[0]), C.c_float(uv[0]), C.c_float(uv[1]), _p(tbn), _p(alb), _p(wn), _p(arm))
+    return alb, wn, arm
+
+
 def shade(f, background: np.ndarray | None = None, rows: tuple[int, int] | None = None, coverage: np.ndarray | None = None):
     """Composition pass on a synth.FrameInputs; returns (color, threshold) uint16 [H, W, 4].
     `coverage`: masks from light_coverage (None: every light covers every pixel)."""

@@ -93,3 +93,23 @@ def test_light_volume_vertex_shader(oracle):
             got = oracle.light_clip_vertex(scene, lights[li:li + 1], verts[vi])
             scale = np.abs(want[li, vi]).max()
             assert np.abs(got - want[li, vi]).max() <= 4 * np.spacing(np.float32(scale)), (li, vi, got, want[li, vi])
+
+
+def test_geometry_pass_shaders(oracle):
+    """gpass.vert.spv (world position, clip position, the re-orthogonalised TBN basis under a rotating,
+    non-uniformly scaling model matrix) and gpass.frag.spv (sRGB / UNORM material lookups, normal mapping)."""
+    g = np.load(os.path.join(GOLDEN, "gpass.npz"))
+    scene = g["scene"][()]
+    d = dict(positions=g["positions"], texcoords=g["texcoords"], normals=g["normals"], tangents=g["tangents"],
+             model=g["model"], albedo=g["tex_albedo"], normal=g["tex_normal"], arm=g["tex_arm"])
+    for i in range(len(g["positions"])):
+        pos, clip, tbn = oracle.gpass_vertex(scene, d, i)
+        assert np.allclose(pos, g["out_position"][i], rtol=2e-6, atol=2e-6), i
+        assert np.allclose(clip, g["gl_position"][i], rtol=1e-5, atol=1e-5), i
+        assert np.allclose(tbn, g["out_tbn"][i], rtol=0, atol=2e-6), i
+    for i in range(len(g["frag_uv"])):
+        alb, wn, arm = oracle.gpass_fragment(d, g["frag_uv"][i], g["frag_tbn"][i])
+        assert np.allclose(alb, g["frag_albedo"][i], atol=2e-6), i
+        assert np.allclose(wn, g["frag_normal"][i][:3], atol=2e-6), i
+        assert np.allclose(arm, g["frag_arm"][i], atol=2e-6), i
+        assert g["frag_normal"][i][3] == 1.0

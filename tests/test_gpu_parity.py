@@ -707,3 +707,49 @@ def test_whole_frame_from_meshes(gpu, oracle):
     assert_bits_equal(P.f16_bits(color), want["color"], "colour")
     assert np.abs(ldr.cpu().numpy().astype(np.int32) - want["ldr"].astype(np.int32)).max() <= 1
     assert (want["color"][..., :3] != 0).any()
+
+
+def test_renderer_renders_a_frame_from_draw_calls_only(gpu, oracle):
+    """Layer 2 with nothing uploaded but scene constants, lights, meshes and materials: EndFrame runs the
+    shadow passes, the geometry pass, the light-volume coverage, composition, bloom and tonemap."""
+    from vulkanrenderer_amd.renderer import HipRenderer
+    w, h, nl = 144, 80, 3
+    draws = _gpass_scene(w, h)
+    f = synth.make_frame(78, w, h, nl, 32, 64, irr_res=8, pref_res=16, lut_res=32)
+    f.scene = _camera_scene((2.0, 1.6, -4.0), aspect=w / h)
+    f.lights = _small_lights(np.random.default_rng(6), nl, 0.05)
+    sphere = synth.make_sphere_mesh()
+    with HipRenderer(w, h, max_lights=4, dir_shadow_res=64, point_shadow_res=32, env_res=16,
+                     irradiance_res=8, prefilter_res=16, prefilter_mips=1, brdf_lut_res=32) as r:
+        r.UploadEnvironmentCubemap(synth.make_env_cube(np.random.default_rng(2), 16))
+        r.CreateIrradianceCubemap(); r.CreatePrefilteredCubemap(); r.CreateBRDFLUTTexture()
+        f.irradiance = r.Read(_lib.TARGET_IRRADIANCE)
+        f.prefilter = r.Read(_lib.TARGET_PREFILTER, mip=0)
+        f.brdf_lut = r.Read(_lib.TARGET_BRDF_LUT)
+        r.SetLightVolumeMesh(*sphere)
+        handles = []
+        for d in draws:
+            mesh = r.CreateMesh(d["positions"], d["triangles"], d["texcoords"], d["normals"], d["tangents"])
+            handles.append((mesh, r.CreateMaterial(d["albedo"], d["normal"], d["arm"]), d["model"]))
+        # the oracle's frame
+        f.albedo, f.normal, f.arm, f.position = oracle.gbuffer(draws, f.scene, w, h)
+        sd = [(d["positions"], d["triangles"], d["model"]) for d in draws]
+        f.cube_shadow = oracle.point_shadow_maps(sd, f.lights, 32)
+        f.dir_shadow = oracle.dir_shadow_map(sd, f.scene["light_space_matrix"], 64)
+        masks = oracle.light_coverage(f.scene, f.lights, sphere[0], sphere[1], w, h)
+        color, thr = oracle.shade(f, coverage=masks)
+        b2 = oracle.bloom_blur(oracle.bloom_blur(thr, True, oracle.WRAP_REPEAT), False, oracle.WRAP_CLAMP)
+        want_ldr = oracle.postprocess(color, b2)
+        for _ in range(2):
+            frame = r.CurrentFrame
+            r.UpdateSceneInfo(f.scene)
+            r.SetLightInfos(f.lights, _lib.COVERAGE_MESH)
+            r.BeginFrame()
+            for mesh, material, model in handles:
+                r.DrawModel(mesh, model, material)
+            r._call(r._lib.vkr_end_frame)
+            assert_bits_equal(r.Read(_lib.TARGET_COLOR, frame), color, "colour")
+            assert_bits_equal(r.Read(_lib.TARGET_THRESHOLD, frame), thr, "threshold")
+            ldr = r.Read(_lib.TARGET_LDR, frame)
+            assert np.abs(ldr.astype(np.int32) - want_ldr.astype(np.int32)).max() <= 1
+        assert (color[..., :3] != 0).any()

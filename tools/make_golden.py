@@ -197,11 +197,64 @@ def light_vert_vectors(spv_dir):
     print("light.vert vectors written")
 
 
+def srgb_to_linear(b):
+    c = np.asarray(b, dtype=np.float32) / np.float32(255.0)
+    return np.where(c <= 0.04045, c / np.float32(12.92), ((c + np.float32(0.055)) / np.float32(1.055)) ** np.float32(2.4)).astype(np.float32)
+
+
+def gpass_vectors(spv_dir):
+    """Outputs of gpass.vert and gpass.frag (the geometry pass) on a few vertices / fragments."""
+    from vulkanrenderer_amd import synth
+    vs = Shader(os.path.join(spv_dir, "gpass.vert.spv"))
+    fs = Shader(os.path.join(spv_dir, "gpass.frag.spv"))
+    rng = np.random.default_rng(31)
+    scene = synth.default_scene_info()
+    cols = lambda m: [np.asarray(r, dtype=np.float32) for r in np.asarray(m, dtype=np.float32).reshape(4, 4)]
+    block = [cols(scene["camera_view"]), cols(scene["camera_projection"]), np.zeros(3, np.float32), np.float32(0)]
+    # a model matrix with rotation, non-uniform scale and translation (row-vector convention)
+    ang = 0.7
+    rot = np.array([[np.cos(ang), 0, -np.sin(ang), 0], [0, 1, 0, 0], [np.sin(ang), 0, np.cos(ang), 0], [0, 0, 0, 1]])
+    model = (np.diag([0.7, 1.3, 0.9, 1.0]) @ rot)
+    model[3, :3] = (0.6, 0.8, -1.2)
+    model = model.astype(np.float32)
+    n = 16
+    pos = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    uv = rng.uniform(-1, 2, (n, 2)).astype(np.float32)
+    nrm = rng.normal(size=(n, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    tan = rng.normal(size=(n, 3)); tan /= np.linalg.norm(tan, axis=1, keepdims=True)   # not orthogonal to the normal on purpose
+    nrm, tan = nrm.astype(np.float32), tan.astype(np.float32)
+    out_pos, out_clip, out_tbn = np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32), np.zeros((n, 9), np.float32)
+    for i in range(n):
+        r = vs.run({0: pos[i], 1: uv[i], 2: nrm[i], 3: tan[i]}, {(0, 0): block, "push": [cols(model)]})["out"]
+        out_pos[i], out_clip[i] = r[1], r["builtin"][0]
+        out_tbn[i] = np.concatenate(r[2])
+    albedo, normal, arm = synth.make_material(np.random.default_rng(32), 16)
+    tex = {(1, 0): Tex2D(np.concatenate([srgb_to_linear(albedo[..., :3]), albedo[..., 3:].astype(np.float32) / 255], -1)),
+           (1, 1): Tex2D(normal.astype(np.float32) / np.float32(255.0)),
+           (1, 2): Tex2D(np.concatenate([srgb_to_linear(arm[..., :3]), arm[..., 3:].astype(np.float32) / 255], -1))}
+    m = 24
+    fuv = rng.uniform(-0.5, 1.5, (m, 2)).astype(np.float32)
+    ftbn = np.zeros((m, 9), np.float32)
+    fa, fn, fm = np.zeros((m, 4), np.float32), np.zeros((m, 4), np.float32), np.zeros((m, 4), np.float32)
+    for i in range(m):
+        ftbn[i] = out_tbn[i % n] * np.float32(rng.uniform(0.8, 1.0))   # interpolated bases are shorter than unit
+        r = fs.run({0: fuv[i], 1: out_pos[i % n], 2: [ftbn[i, 0:3], ftbn[i, 3:6], ftbn[i, 6:9]]}, tex)["out"]
+        fa[i], fn[i], fm[i] = r[0], r[1], r[2]
+    np.savez_compressed(os.path.join(OUT, "gpass.npz"), scene=scene, model=model, positions=pos, texcoords=uv, normals=nrm, tangents=tan,
+                        out_position=out_pos, gl_position=out_clip, out_tbn=out_tbn,
+                        tex_albedo=albedo, tex_normal=normal, tex_arm=arm, frag_uv=fuv, frag_tbn=ftbn,
+                        frag_albedo=fa, frag_normal=fn, frag_arm=fm)
+    print("gpass vectors written")
+
+
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     spv = args[0] if args else "/root/reference/compiled_shaders"
     if "--only-light-vert" in sys.argv:
         light_vert_vectors(spv)
+    elif "--only-gpass" in sys.argv:
+        gpass_vectors(spv)
     else:
         main(spv)
         light_vert_vectors(spv)
+        gpass_vectors(spv)

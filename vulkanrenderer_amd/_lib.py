@@ -155,7 +155,9 @@ PROTOTYPES = {
     "vkr_set_lights": [_vp, _vp, _i32, _i32],
     "vkr_set_light_volume_mesh": [_vp, _vp, _i32, _vp, _i32],
     "vkr_create_mesh": [_vp, _vp, _i32, _vp, _i32, C.POINTER(C.c_int32)],
-    "vkr_draw_model": [_vp, _i32, _vp],
+    "vkr_set_mesh_attributes": [_vp, _i32, _vp, _vp, _vp],
+    "vkr_create_material": [_vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i32, C.POINTER(C.c_int32)],
+    "vkr_draw_model": [_vp, _i32, _i32, _vp],
     "vkr_begin_frame": [_vp],
     "vkr_end_frame": [_vp],
     "vkr_current_frame": [_vp],

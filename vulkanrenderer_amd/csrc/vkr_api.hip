@@ -52,9 +52,14 @@ struct vkr_ctx {
     float *mesh_verts = nullptr;    // light-volume mesh (vkr_set_light_volume_mesh)
     uint32_t *mesh_indices = nullptr;
     int mesh_n_verts = 0, mesh_n_tris = 0;
-    struct Mesh { float *positions; uint32_t *indices; int n_verts, n_tris; };
+    struct Mesh { float *positions; uint32_t *indices; int n_verts, n_tris; float *texcoords, *normals, *tangents; };
+    struct Material { VkrTexture albedo, normal, arm; };
     std::vector<Mesh> meshes;            // vkr_create_mesh
+    std::vector<Material> materials;     // vkr_create_material
     std::vector<VkrMeshDraw> draw_calls; // vkr_draw_model since the last BeginFrame (solidModelDrawCalls)
+    std::vector<int> draw_mesh, draw_material;  // per draw call; material -1: the draw only casts shadows
+    void *gp_workspace = nullptr;        // visibility keys + draw records of the geometry pass
+    int64_t gp_workspace_bytes = 0;
     bool cubes_tiled = false;       // point shadow cubes are stored VKR_CUBE_LAYOUT_TILED_8X4
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timing_valid = false;
@@ -105,7 +110,14 @@ static void destroy(vkr_ctx *c)
         if (f.lights) (void)hipFree(f.lights);
     }
     void *ibl[] = {c->env, c->env_tiled, c->irradiance, c->brdf_lut, c->cube_staging, c->mesh_verts, c->mesh_indices};
-    for (auto &m : c->meshes) { (void)hipFree(m.positions); (void)hipFree(m.indices); }
+    for (auto &m : c->meshes) {
+        (void)hipFree(m.positions); (void)hipFree(m.indices);
+        if (m.texcoords) (void)hipFree(m.texcoords);
+        if (m.normals) (void)hipFree(m.normals);
+        if (m.tangents) (void)hipFree(m.tangents);
+    }
+    for (auto &m : c->materials) { (void)hipFree((void *)m.albedo.rgba8); (void)hipFree((void *)m.normal.rgba8); (void)hipFree((void *)m.arm.rgba8); }
+    if (c->gp_workspace) (void)hipFree(c->gp_workspace);
     for (void *p : ibl) if (p) (void)hipFree(p);
     for (void *p : c->prefilter) if (p) (void)hipFree(p);
     for (hipEvent_t e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -115,6 +127,7 @@ static void destroy(vkr_ctx *c)
 
 static int32_t run_coverage(vkr_ctx *c, Frame &f);
 static int32_t run_shadow_passes(vkr_ctx *c, Frame &f);
+static int32_t run_geometry_pass(vkr_ctx *c, Frame &f);
 
 #define VKR_CTX(c)                                                   \
     VKR_REQUIRE((c) != nullptr, "%s: context is null", __func__);    \
@@ -139,6 +152,39 @@ static int32_t fill_shade_args(vkr_ctx *c, Frame &f, VkrShadeArgs &a)
     a.out_color = f.color; a.out_threshold = f.threshold;
     a.coverage_masks = f.coverage == VKR_COVERAGE_MESH ? f.coverage_buf : nullptr;
     return VKR_OK;
+}
+
+static constexpr int GP_MAX_DRAWS = 1024;  // draw records the geometry-pass workspace has room for
+
+// The geometry render pass of EndFrame (VulkanRenderer.cs:378-404).  It runs when every draw call of the
+// frame has a material and vertex attributes; otherwise the uploaded G-buffer is used.
+static int32_t run_geometry_pass(vkr_ctx *c, Frame &f)
+{
+    if (c->draw_calls.empty()) return VKR_OK;
+    std::vector<VkrGpassDraw> draws(c->draw_calls.size());
+    for (size_t k = 0; k < draws.size(); k++) {
+        const vkr_ctx::Mesh &m = c->meshes[c->draw_mesh[k]];
+        if (c->draw_material[k] < 0 || !m.texcoords) return VKR_OK;
+        const vkr_ctx::Material &mat = c->materials[c->draw_material[k]];
+        VkrGpassDraw &d = draws[k];
+        d.positions = m.positions; d.texcoords = m.texcoords; d.normals = m.normals; d.tangents = m.tangents;
+        d.n_verts = m.n_verts; d.indices = m.indices; d.n_tris = m.n_tris;
+        memcpy(d.model, c->draw_calls[k].model, sizeof(d.model));
+        d.albedo = mat.albedo; d.normal = mat.normal; d.arm = mat.arm;
+    }
+    if (draws.size() > (size_t)GP_MAX_DRAWS) return fail(VKR_ERR_UNSUPPORTED, "more than %d draw calls in a frame", GP_MAX_DRAWS);
+    if (!c->gp_workspace) {
+        c->gp_workspace_bytes = vkr_gbuffer_workspace_bytes(c->cfg.width, c->cfg.height, GP_MAX_DRAWS);
+        VKR_HIP_CHECK(hipMalloc(&c->gp_workspace, (size_t)c->gp_workspace_bytes));
+    }
+    VkrGpassArgs a;
+    memset(&a, 0, sizeof(a));
+    a.draws = draws.data(); a.n_draws = (int32_t)draws.size();
+    a.scene = f.scene;
+    a.width = c->cfg.width; a.rows = c->cfg.height; a.frame_rows = c->cfg.height; a.row0 = 0;
+    a.albedo = f.gbuf[0]; a.normal = f.gbuf[1]; a.arm = f.gbuf[2]; a.position = f.gbuf[3];
+    a.workspace = c->gp_workspace; a.workspace_bytes = c->gp_workspace_bytes;
+    return vkr_gbuffer(&a, c->stream);
 }
 
 // The shadow render passes of EndFrame (VulkanRenderer.cs:325-376, 406-428) over the frame's draw calls.
@@ -288,6 +334,7 @@ extern "C" int32_t vkr_resize(vkr_ctx *c, int32_t width, int32_t height)
     free_frame_sized(c);
     c->cfg.width = width; c->cfg.height = height;
     c->timing_valid = false;
+    if (c->gp_workspace) { (void)hipFree(c->gp_workspace); c->gp_workspace = nullptr; }
     return alloc_frame_sized(c);
 }
 
@@ -321,6 +368,7 @@ extern "C" int32_t vkr_begin_frame(vkr_ctx *c)
     if (c->in_frame) return fail(VKR_ERR_ORDER, "Tried to begin frame before previous frame was finished!");  // VulkanRenderer.cs:288
     c->in_frame = true;
     c->draw_calls.clear();  // VulkanRenderer.cs:316
+    c->draw_mesh.clear(); c->draw_material.clear();
     return VKR_OK;
 }
 
@@ -362,7 +410,7 @@ extern "C" int32_t vkr_create_mesh(vkr_ctx *c, const float *positions, int32_t n
     VKR_REQUIRE(positions && indices && mesh_out && n_verts > 0 && n_tris > 0, "vkr_create_mesh: mesh missing");
     for (int64_t i = 0; i < (int64_t)n_tris * 3; i++)
         VKR_REQUIRE(indices[i] < (uint32_t)n_verts, "vkr_create_mesh: index %u at %lld is outside the %d vertices", indices[i], (long long)i, n_verts);
-    vkr_ctx::Mesh m = {nullptr, nullptr, n_verts, n_tris};
+    vkr_ctx::Mesh m = {nullptr, nullptr, n_verts, n_tris, nullptr, nullptr, nullptr};
     VKR_HIP_CHECK(hipMalloc((void **)&m.positions, (size_t)n_verts * 12));
     hipError_t e = hipMalloc((void **)&m.indices, (size_t)n_tris * 12);
     int32_t rc = e == hipSuccess ? upload(c, m.positions, positions, (size_t)n_verts * 12) : fail(VKR_ERR_HIP, "vkr_create_mesh: %s", hipGetErrorString(e));
@@ -373,10 +421,57 @@ extern "C" int32_t vkr_create_mesh(vkr_ctx *c, const float *positions, int32_t n
     return VKR_OK;
 }
 
-extern "C" int32_t vkr_draw_model(vkr_ctx *c, int32_t mesh, const float *model16)
+extern "C" int32_t vkr_set_mesh_attributes(vkr_ctx *c, int32_t mesh, const float *texcoords, const float *normals, const float *tangents)
+{
+    VKR_CTX(c);
+    VKR_REQUIRE(mesh >= 0 && mesh < (int32_t)c->meshes.size(), "vkr_set_mesh_attributes: unknown mesh %d", mesh);
+    VKR_REQUIRE(texcoords && normals && tangents, "vkr_set_mesh_attributes: an attribute array is null");
+    vkr_ctx::Mesh &m = c->meshes[mesh];
+    const size_t n = (size_t)m.n_verts;
+    if (!m.texcoords) {
+        VKR_HIP_CHECK(hipMalloc((void **)&m.texcoords, n * 8));
+        VKR_HIP_CHECK(hipMalloc((void **)&m.normals, n * 12));
+        VKR_HIP_CHECK(hipMalloc((void **)&m.tangents, n * 12));
+    }
+    int32_t rc = upload(c, m.texcoords, texcoords, n * 8);
+    if (rc == VKR_OK) rc = upload(c, m.normals, normals, n * 12);
+    if (rc == VKR_OK) rc = upload(c, m.tangents, tangents, n * 12);
+    return rc;
+}
+
+extern "C" int32_t vkr_create_material(vkr_ctx *c, const void *albedo, int32_t aw, int32_t ah, const void *normal, int32_t nw, int32_t nh,
+                                       const void *arm, int32_t mw, int32_t mh, int32_t *material_out)
+{
+    VKR_CTX(c);
+    VKR_REQUIRE(albedo && normal && arm && material_out, "vkr_create_material: an image is null");
+    VKR_REQUIRE(aw > 0 && ah > 0 && nw > 0 && nh > 0 && mw > 0 && mh > 0, "vkr_create_material: bad image size");
+    vkr_ctx::Material m;
+    memset(&m, 0, sizeof(m));
+    const void *src[3] = {albedo, normal, arm};
+    VkrTexture *dst[3] = {&m.albedo, &m.normal, &m.arm};
+    const int w[3] = {aw, nw, mw}, h[3] = {ah, nh, mh};
+    int32_t rc = VKR_OK;
+    for (int k = 0; k < 3 && rc == VKR_OK; k++) {
+        void *dev = nullptr;
+        hipError_t e = hipMalloc(&dev, (size_t)w[k] * h[k] * 4);
+        if (e != hipSuccess) { rc = fail(VKR_ERR_HIP, "vkr_create_material: %s", hipGetErrorString(e)); break; }
+        dst[k]->rgba8 = dev; dst[k]->width = w[k]; dst[k]->height = h[k];
+        rc = upload(c, dev, src[k], (size_t)w[k] * h[k] * 4);
+    }
+    if (rc != VKR_OK) {
+        for (VkrTexture *t : dst) if (t->rgba8) (void)hipFree((void *)t->rgba8);
+        return rc;
+    }
+    c->materials.push_back(m);
+    *material_out = (int32_t)c->materials.size() - 1;
+    return VKR_OK;
+}
+
+extern "C" int32_t vkr_draw_model(vkr_ctx *c, int32_t mesh, int32_t material, const float *model16)
 {
     VKR_CTX(c);
     VKR_REQUIRE(mesh >= 0 && mesh < (int32_t)c->meshes.size(), "vkr_draw_model: unknown mesh %d", mesh);
+    VKR_REQUIRE(material >= -1 && material < (int32_t)c->materials.size(), "vkr_draw_model: unknown material %d", material);
     VKR_REQUIRE(model16 != nullptr, "vkr_draw_model: model matrix is null");
     if (!c->in_frame) return fail(VKR_ERR_ORDER, "vkr_draw_model: call between BeginFrame and EndFrame");
     const vkr_ctx::Mesh &m = c->meshes[mesh];
@@ -384,6 +479,7 @@ extern "C" int32_t vkr_draw_model(vkr_ctx *c, int32_t mesh, const float *model16
     d.positions = m.positions; d.n_verts = m.n_verts; d.indices = m.indices; d.n_tris = m.n_tris;
     memcpy(d.model, model16, sizeof(d.model));
     c->draw_calls.push_back(d);
+    c->draw_mesh.push_back(mesh); c->draw_material.push_back(material);
     return VKR_OK;
 }
 
@@ -512,6 +608,7 @@ extern "C" int32_t vkr_pass_composition(vkr_ctx *c)
     int32_t rc = fill_shade_args(c, c->frames[c->frame], a);
     if (rc != VKR_OK) return rc;
     if ((rc = run_shadow_passes(c, c->frames[c->frame])) != VKR_OK) return rc;
+    if ((rc = run_geometry_pass(c, c->frames[c->frame])) != VKR_OK) return rc;
     if ((rc = run_coverage(c, c->frames[c->frame])) != VKR_OK) return rc;
     return vkr_shade(&a, c->stream);
 }
@@ -543,7 +640,8 @@ extern "C" int32_t vkr_end_frame(vkr_ctx *c)
     int32_t rc = fill_shade_args(c, f, a);
     if (rc != VKR_OK) return rc;
     VKR_HIP_CHECK(hipEventRecord(c->ev[0], c->stream));
-    if ((rc = run_shadow_passes(c, f)) != VKR_OK) return rc;
+    if ((rc = run_shadow_passes(c, f)) != VKR_OK) return rc;   // EndFrame's order: point shadows, geometry, directional shadow
+    if ((rc = run_geometry_pass(c, f)) != VKR_OK) return rc;
     if ((rc = run_coverage(c, f)) != VKR_OK) return rc;  // both counted with the composition pass in the timing
     if ((rc = vkr_shade(&a, c->stream)) != VKR_OK) return rc;
     VKR_HIP_CHECK(hipEventRecord(c->ev[1], c->stream));

@@ -126,20 +126,36 @@ class HipRenderer:
         infos = np.ascontiguousarray(infos)
         self._call(self._lib.vkr_set_lights, _host_ptr(infos) if len(infos) else C.c_void_p(0), len(infos), coverage)
 
-    def CreateMesh(self, verts: np.ndarray, triangles: np.ndarray) -> int:
-        """Keeps a mesh on the device (Mesh.cs); returns its handle for DrawModel."""
+    def CreateMesh(self, verts: np.ndarray, triangles: np.ndarray, texcoords=None, normals=None, tangents=None) -> int:
+        """Keeps a mesh on the device (Mesh.cs); returns its handle for DrawModel.  With texture coordinates,
+        normals and tangents the mesh can take part in the geometry pass."""
         verts = np.ascontiguousarray(verts, dtype=np.float32)
         triangles = np.ascontiguousarray(triangles, dtype=np.uint32)
         handle = C.c_int32(-1)
         self._call(self._lib.vkr_create_mesh, _host_ptr(verts), len(verts), _host_ptr(triangles), len(triangles), C.byref(handle))
+        if texcoords is not None:
+            uv, nrm, tan = (np.ascontiguousarray(a, dtype=np.float32) for a in (texcoords, normals, tangents))
+            assert len(uv) == len(nrm) == len(tan) == len(verts)
+            self._call(self._lib.vkr_set_mesh_attributes, handle.value, _host_ptr(uv), _host_ptr(nrm), _host_ptr(tan))
         return handle.value
 
-    def DrawModel(self, mesh: int, model_matrix) -> None:
-        """VulkanRenderer.DrawModel (VulkanRenderer.cs:630-633): queues a draw call for this frame; EndFrame then
-        renders the shadow maps from the frame's draw calls."""
+    def CreateMaterial(self, albedo: np.ndarray, normal: np.ndarray, arm: np.ndarray) -> int:
+        """Material.cs: three RGBA8 images [h, w, 4] (albedo sRGB, normal map, ao/roughness/metalness sRGB)."""
+        imgs = [np.ascontiguousarray(a, dtype=np.uint8) for a in (albedo, normal, arm)]
+        handle = C.c_int32(-1)
+        args = []
+        for im in imgs:
+            assert im.ndim == 3 and im.shape[2] == 4
+            args += [_host_ptr(im), im.shape[1], im.shape[0]]
+        self._call(self._lib.vkr_create_material, *args, C.byref(handle))
+        return handle.value
+
+    def DrawModel(self, mesh: int, model_matrix, material: int = -1) -> None:
+        """VulkanRenderer.DrawModel (VulkanRenderer.cs:630-633): queues a draw call for this frame.  EndFrame
+        renders the shadow maps from the frame's draw calls, and the G-buffer too when every draw has a material."""
         m = np.ascontiguousarray(model_matrix, dtype=np.float32).ravel()
         assert m.size == 16
-        self._call(self._lib.vkr_draw_model, mesh, _host_ptr(m))
+        self._call(self._lib.vkr_draw_model, mesh, material, _host_ptr(m))
 
     def SetLightVolumeMesh(self, verts: np.ndarray, triangles: np.ndarray) -> None:
         """The mesh each light volume is an instance of (the reference's sphereMesh, VulkanRenderer.cs:78,269);
