@@ -753,3 +753,33 @@ def test_renderer_renders_a_frame_from_draw_calls_only(gpu, oracle):
             ldr = r.Read(_lib.TARGET_LDR, frame)
             assert np.abs(ldr.astype(np.int32) - want_ldr.astype(np.int32)).max() <= 1
         assert (color[..., :3] != 0).any()
+
+
+def test_large_triangles_are_shared_by_the_wave(gpu, oracle):
+    """Triangles whose bounding boxes hold far more samples than one lane should walk (a floor of two
+    triangles under the scene, seen by the camera and by the lights) give the oracle's bits too."""
+    torch, P = _torch(), _passes()
+    w, h = 256, 144
+    floor = (np.array([[-6, -0.6, -6], [6, -0.6, -6], [6, -0.6, 6], [-6, -0.6, 6], [-6, -0.9, -6], [6, -0.9, -6], [6, -0.9, 6], [-6, -0.9, 6]], dtype=np.float32),
+             np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4], [1, 2, 6], [1, 6, 5], [2, 3, 7], [2, 7, 6], [3, 0, 4], [3, 4, 7]], dtype=np.uint32))
+    draws = _gpass_scene(w, h)
+    uv, nrm, tan = synth.mesh_attributes(*floor, uv_scale=0.1)
+    alb, nmap, arm = synth.make_material(np.random.default_rng(50), 32)
+    draws.append(dict(positions=floor[0], texcoords=uv, normals=nrm, tangents=tan, triangles=floor[1], model=np.eye(4),
+                      albedo=alb, normal=nmap, arm=arm))
+    scene = _camera_scene((2.0, 1.6, -4.0), aspect=w / h)
+    want = oracle.gbuffer(draws, scene, w, h)
+    assert (want[0][..., 3] != 0).mean() > 0.6
+    got = P.gbuffer(_gpass_device_draws(draws, gpu), scene, w, h, gpu)
+    for name, g, wv in zip(("albedo", "normal", "arm", "position"), got, want):
+        assert_bits_equal(P.f16_bits(g), wv, f"G-buffer {name}")
+    lights = synth.make_lights(np.random.default_rng(18), 2)
+    sd = [(d["positions"], d["triangles"], d["model"]) for d in draws]
+    want_cube = oracle.point_shadow_maps(sd, lights, 128)
+    dev_lights = torch.from_numpy(np.frombuffer(lights.tobytes(), dtype=np.uint8).copy()).to(gpu)
+    got_cube, _ = P.point_shadow_maps(_device_draws(sd, gpu), dev_lights, 2, 128, tiled=False)
+    assert np.array_equal(got_cube.cpu().numpy().view(np.uint32), want_cube.view(np.uint32))
+    ls = synth.default_scene_info()["light_space_matrix"]
+    want_dir = oracle.dir_shadow_map(sd, ls, 256)
+    got_dir = P.dir_shadow_map(_device_draws(sd, gpu), ls, 256, gpu)
+    assert np.array_equal(got_dir.cpu().numpy().view(np.uint32), want_dir.view(np.uint32))

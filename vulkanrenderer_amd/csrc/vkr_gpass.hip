@@ -84,38 +84,38 @@ __global__ __launch_bounds__(256) void gpass_visibility_kernel(const GpassParams
 {
     const VkrGpassDraw &d = p.draws[p.draw];
     const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= d.n_tris) return;
-    float clip[3][4];
+    bool have = t < d.n_tris;  // lanes past the end stay: the wave shares large triangles
+    float clip[3][4] = {};
+    int bx0 = 0, by0 = 0, bx1 = -1, by1 = -1;
+    if (have) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        GpVertex v;
-        gpass_vertex(d, p.vp, d.indices[3 * t + k], v, false);
+        for (int k = 0; k < 3; k++) {
+            GpVertex v;
+            gpass_vertex(d, p.vp, d.indices[3 * t + k], v, false);
 #pragma unroll
-        for (int j = 0; j < 4; j++) clip[k][j] = v.clip[j];
-    }
-    STri tr;
-    raster_setup(clip, tr);
-    if (!(tr.D < 0.0)) return;  // BACK faces (D > 0) and degenerate triangles are culled
-    raster_flip(tr);
-    int qx0, qy0, qx1, qy1, rx0, ry0, rx1, ry1;
-    if (!shadow_bbox(clip, p.width, qx0, qy0, qx1, qy1)) return;
-    if (!shadow_bbox(clip, p.frame_rows, rx0, ry0, rx1, ry1)) return;
-    const int by0 = max(ry0 - p.row0, 0), by1 = min(ry1 - p.row0, p.rows - 1);
-    const double sx = 2.0 / (double)p.width, sy = 2.0 / (double)p.frame_rows;
-    const unsigned long long id = (unsigned long long)(p.tri_base + (unsigned)t);
-    for (int y = by0; y <= by1; y++) {
-        const double yn = __builtin_fma((double)(p.row0 + y) + 0.5, sy, -1.0);
-        for (int x = qx0; x <= qx1; x++) {
-            const double xn = __builtin_fma((double)x + 0.5, sx, -1.0);
-            const double e0 = s_edge(tr, 0, xn, yn), e1 = s_edge(tr, 1, xn, yn), e2 = s_edge(tr, 2, xn, yn);
-            if (!(e0 >= 0.0 && e1 >= 0.0 && e2 >= 0.0 && (e0 + e1) + e2 > 0.0)) continue;
-            const double zs = __builtin_fma(e2, tr.z[2], __builtin_fma(e1, tr.z[1], e0 * tr.z[0]));
-            if (!(zs >= 0.0 && zs <= tr.D)) continue;
-            const float depth = (float)(zs / tr.D) + 0.0f;
-            const unsigned long long key = ((unsigned long long)__builtin_bit_cast(unsigned int, depth) << 32) | id;
-            atomicMin(p.vis + (size_t)y * p.width + x, key);
+            for (int j = 0; j < 4; j++) clip[k][j] = v.clip[j];
+        }
+        STri tr;
+        raster_setup(clip, tr);
+        int qy0, qy1, rx0, rx1, ry0, ry1;
+        // BACK faces (D > 0) and degenerate triangles are culled
+        have = tr.D < 0.0 && shadow_bbox(clip, p.width, bx0, qy0, bx1, qy1) && shadow_bbox(clip, p.frame_rows, rx0, ry0, rx1, ry1);
+        if (have) {
+            by0 = max(ry0 - p.row0, 0); by1 = min(ry1 - p.row0, p.rows - 1);
+            have = by0 <= by1;
         }
     }
+    const double sx = 2.0 / (double)p.width, sy = 2.0 / (double)p.frame_rows;
+    raster_boxes<true>(have, clip, clip, p.tri_base + (unsigned)t, bx0, by0, bx1, by1, [&](const STri &tr, const float (&)[3][4], unsigned id, int x, int y) {
+        const double xn = __builtin_fma((double)x + 0.5, sx, -1.0), yn = __builtin_fma((double)(p.row0 + y) + 0.5, sy, -1.0);
+        const double e0 = s_edge(tr, 0, xn, yn), e1 = s_edge(tr, 1, xn, yn), e2 = s_edge(tr, 2, xn, yn);
+        if (!(e0 >= 0.0 && e1 >= 0.0 && e2 >= 0.0 && (e0 + e1) + e2 > 0.0)) return;
+        const double zs = __builtin_fma(e2, tr.z[2], __builtin_fma(e1, tr.z[1], e0 * tr.z[0]));
+        if (!(zs >= 0.0 && zs <= tr.D)) return;
+        const float depth = (float)(zs / tr.D) + 0.0f;
+        const unsigned long long key = ((unsigned long long)__builtin_bit_cast(unsigned int, depth) << 32) | (unsigned long long)id;
+        atomicMin(p.vis + (size_t)y * p.width + x, key);
+    });
 }
 
 // textureSampler on a single-level RGBA8 image: LINEAR, REPEAT; srgb: r, g, b are decoded before filtering

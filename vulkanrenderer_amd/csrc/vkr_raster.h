@@ -86,4 +86,50 @@ VKR_DEV bool shadow_bbox(const float (&c)[3][4], int res, int &bx0, int &by0, in
     return true;
 }
 
+VKR_DEV float readlane_f(float x, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src)); }
+
+static constexpr int RASTER_BIG = 1024;  // bounding boxes with more samples than this are walked by the whole wave
+
+// Calls pixel(tri, attr, tag, i, j) for every sample (i, j) of the bounding box of each lane's
+// triangle (`have`: the lane has one).  A lane walks a small box itself; a large box is taken over
+// by the whole wave -- its owner's corners are broadcast, every lane redoes the (deterministic)
+// setup and takes every 64th sample -- so one screen-filling triangle does not leave 63 lanes idle.
+// Every lane of the wave must call this (no early returns before it).  FLIP: front faces were kept.
+template <bool FLIP, typename F>
+VKR_DEV void raster_boxes(bool have, const float (&clip)[3][4], const float (&attr)[3][4], unsigned tag,
+                          int bx0, int by0, int bx1, int by1, F pixel)
+{
+    const int w = have ? bx1 - bx0 + 1 : 0, h = have ? by1 - by0 + 1 : 0;
+    const bool big = have && (long long)w * h > RASTER_BIG;
+    if (have && !big) {
+        STri t;
+        raster_setup(clip, t);
+        if (FLIP) raster_flip(t);
+        for (int j = by0; j <= by1; j++)
+            for (int i = bx0; i <= bx1; i++) pixel(t, attr, tag, i, j);
+    }
+    unsigned long long todo = __ballot(big);
+    const int lane = (int)__lane_id();
+    while (todo) {  // wave-uniform
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        float c2[3][4], a2[3][4];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) { c2[k][j] = readlane_f(clip[k][j], src); a2[k][j] = readlane_f(attr[k][j], src); }
+        const unsigned tag2 = (unsigned)__builtin_amdgcn_readlane((int)tag, src);
+        const int x0 = __builtin_amdgcn_readlane(bx0, src), y0 = __builtin_amdgcn_readlane(by0, src);
+        const int w2 = __builtin_amdgcn_readlane(w, src), h2 = __builtin_amdgcn_readlane(h, src);
+        STri t;
+        raster_setup(c2, t);
+        if (FLIP) raster_flip(t);
+        const long long total = (long long)w2 * h2;
+        for (long long q = lane; q < total; q += 64) {
+            const int jj = (int)(q / w2), ii = (int)(q - (long long)jj * w2);
+            pixel(t, a2, tag2, x0 + ii, y0 + jj);
+        }
+    }
+}
+
 }  // namespace vkr

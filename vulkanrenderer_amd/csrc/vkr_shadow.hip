@@ -54,39 +54,41 @@ VKR_DEV size_t depth_texel_index(int res, int i, int j, bool tiled)
     return (size_t)(((unsigned)j >> 2) * ((unsigned)res >> 3) + ((unsigned)i >> 3)) * 32u + ((unsigned)j & 3u) * 8u + ((unsigned)i & 7u);
 }
 
-// One triangle into one res x res depth image; world = corners' world positions (point lights) or null.
-VKR_DEV void shadow_raster(const float (&clip)[3][4], const float (*world)[4], const float *light_pos, float inv_far, int res, bool tiled, float *img)
+// The triangles of the wave's lanes into one res x res depth image each (`img` may differ per lane only
+// through `have`: all lanes of a call target the same image).  POINT: world = corners' world positions
+// and the depth is point_shadow.frag's; otherwise the fixed-function z / w.
+template <bool POINT>
+VKR_DEV void shadow_raster(bool valid, const float (&clip)[3][4], const float (&world)[3][4], const float *light_pos, float inv_far, int res, bool tiled, float *img)
 {
-    STri t;
-    raster_setup(clip, t);
-    if (!(t.D > 0.0)) return;  // front faces and degenerate triangles are culled
-    int bx0, by0, bx1, by1;
-    if (!shadow_bbox(clip, res, bx0, by0, bx1, by1)) return;
-    const double sc = 2.0 / (double)res;
-    for (int j = by0; j <= by1; j++) {
-        const double yn = __builtin_fma((double)j + 0.5, sc, -1.0);
-        for (int i = bx0; i <= bx1; i++) {
-            const double xn = __builtin_fma((double)i + 0.5, sc, -1.0);
-            const double e0 = s_edge(t, 0, xn, yn), e1 = s_edge(t, 1, xn, yn), e2 = s_edge(t, 2, xn, yn);
-            const double s = (e0 + e1) + e2;
-            if (!(e0 >= 0.0 && e1 >= 0.0 && e2 >= 0.0 && s > 0.0)) continue;
-            const double zs = __builtin_fma(e2, t.z[2], __builtin_fma(e1, t.z[1], e0 * t.z[0]));
-            if (!(zs >= 0.0 && zs <= t.D)) continue;
-            float depth;
-            if (world) {  // point_shadow.frag:11-16 on the interpolated world position
-                float pw[3];
-#pragma unroll
-                for (int k = 0; k < 3; k++)
-                    pw[k] = (float)(__builtin_fma(e2, (double)world[2][k], __builtin_fma(e1, (double)world[1][k], e0 * (double)world[0][k])) / s);
-                const f3 d = mk3(pw[0] - light_pos[0], pw[1] - light_pos[1], pw[2] - light_pos[2]);
-                depth = sqrt_rn(dot3(d, d)) * inv_far;
-            } else {
-                depth = (float)(zs / t.D) + 0.0f;  // z / w of the fixed-function pipeline (-0 becomes +0)
-            }
-            if (depth < 1.0f)  // CompareOp.Less against the cleared 1.0 and every earlier write; depth >= 0 here
-                atomicMin((unsigned int *)(img + depth_texel_index(res, i, j, tiled)), __builtin_bit_cast(unsigned int, depth));
-        }
+    int bx0 = 0, by0 = 0, bx1 = -1, by1 = -1;
+    bool have = valid;
+    if (have) {
+        STri t;
+        raster_setup(clip, t);
+        have = t.D > 0.0 && shadow_bbox(clip, res, bx0, by0, bx1, by1);  // front faces and degenerate triangles are culled
     }
+    const double sc = 2.0 / (double)res;
+    raster_boxes<false>(have, clip, world, 0u, bx0, by0, bx1, by1, [&](const STri &t, const float (&wp)[3][4], unsigned, int i, int j) {
+        const double xn = __builtin_fma((double)i + 0.5, sc, -1.0), yn = __builtin_fma((double)j + 0.5, sc, -1.0);
+        const double e0 = s_edge(t, 0, xn, yn), e1 = s_edge(t, 1, xn, yn), e2 = s_edge(t, 2, xn, yn);
+        const double s = (e0 + e1) + e2;
+        if (!(e0 >= 0.0 && e1 >= 0.0 && e2 >= 0.0 && s > 0.0)) return;
+        const double zs = __builtin_fma(e2, t.z[2], __builtin_fma(e1, t.z[1], e0 * t.z[0]));
+        if (!(zs >= 0.0 && zs <= t.D)) return;
+        float depth;
+        if (POINT) {  // point_shadow.frag:11-16 on the interpolated world position
+            float pw[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                pw[k] = (float)(__builtin_fma(e2, (double)wp[2][k], __builtin_fma(e1, (double)wp[1][k], e0 * (double)wp[0][k])) / s);
+            const f3 d = mk3(pw[0] - light_pos[0], pw[1] - light_pos[1], pw[2] - light_pos[2]);
+            depth = sqrt_rn(dot3(d, d)) * inv_far;
+        } else {
+            depth = (float)(zs / t.D) + 0.0f;  // z / w of the fixed-function pipeline (-0 becomes +0)
+        }
+        if (depth < 1.0f)  // CompareOp.Less against the cleared 1.0 and every earlier write; depth >= 0 here
+            atomicMin((unsigned int *)(img + depth_texel_index(res, i, j, tiled)), __builtin_bit_cast(unsigned int, depth));
+    });
 }
 
 __global__ __launch_bounds__(256) void point_shadow_kernel(const ShadowParams p)
@@ -98,14 +100,16 @@ __global__ __launch_bounds__(256) void point_shadow_kernel(const ShadowParams p)
     if (threadIdx.x < 96) shadow_face_matrix_elem(eye, threadIdx.x >> 4, p.far_plane, threadIdx.x & 15, s_m[threadIdx.x >> 4]);
     __syncthreads();
     const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= p.n_tris) return;
-    float world[3][4];
-    const unsigned vmax = (unsigned)p.n_verts - 1u;
+    const bool valid = t < p.n_tris;  // lanes past the end stay: the wave shares large triangles
+    float world[3][4] = {};
+    if (valid) {
+        const unsigned vmax = (unsigned)p.n_verts - 1u;
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const float *v = p.positions + 3 * (size_t)min(p.indices[3 * t + k], vmax);
-        const float v4[4] = {v[0], v[1], v[2], 1.0f};
-        mat4_vec4(p.model, v4, world[k]);  // point_shadow.vert:12
+        for (int k = 0; k < 3; k++) {
+            const float *v = p.positions + 3 * (size_t)min(p.indices[3 * t + k], vmax);
+            const float v4[4] = {v[0], v[1], v[2], 1.0f};
+            mat4_vec4(p.model, v4, world[k]);  // point_shadow.vert:12
+        }
     }
     const float inv_far = rcp_rn(p.far_plane);
     const size_t face_texels = (size_t)p.res * p.res;
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(256) void point_shadow_kernel(const ShadowParams p)
         float clip[3][4];
 #pragma unroll
         for (int k = 0; k < 3; k++) mat4_vec4(s_m[face], world[k], clip[k]);  // point_shadow.geom:20
-        shadow_raster(clip, world, eye, inv_far, p.res, p.tiled != 0, p.out + ((size_t)li * 6 + face) * face_texels);
+        shadow_raster<true>(valid, clip, world, eye, inv_far, p.res, p.tiled != 0, p.out + ((size_t)li * 6 + face) * face_texels);
     }
 }
 
@@ -123,16 +127,18 @@ __global__ __launch_bounds__(256) void dir_shadow_kernel(const ShadowParams p)
     if (threadIdx.x < 16) s_mvp[threadIdx.x] = mat4_mul_elem(p.model, p.light_space, threadIdx.x >> 2, threadIdx.x & 3);  // depth.vert:13
     __syncthreads();
     const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= p.n_tris) return;
-    float clip[3][4];
-    const unsigned vmax = (unsigned)p.n_verts - 1u;
+    const bool valid = t < p.n_tris;
+    float clip[3][4] = {};
+    if (valid) {
+        const unsigned vmax = (unsigned)p.n_verts - 1u;
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const float *v = p.positions + 3 * (size_t)min(p.indices[3 * t + k], vmax);
-        const float v4[4] = {v[0], v[1], v[2], 1.0f};
-        mat4_vec4(s_mvp, v4, clip[k]);
+        for (int k = 0; k < 3; k++) {
+            const float *v = p.positions + 3 * (size_t)min(p.indices[3 * t + k], vmax);
+            const float v4[4] = {v[0], v[1], v[2], 1.0f};
+            mat4_vec4(s_mvp, v4, clip[k]);
+        }
     }
-    shadow_raster(clip, nullptr, nullptr, 0.0f, p.res, false, p.out);
+    shadow_raster<false>(valid, clip, clip, nullptr, 0.0f, p.res, false, p.out);
 }
 
 __global__ __launch_bounds__(256) void fill_depth_kernel(float4 *out, size_t n4)
