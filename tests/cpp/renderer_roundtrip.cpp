@@ -6,6 +6,9 @@
 // input file (little endian): int32 w, h, n_lights, dir_res, cube_res, env_res, irr_res, pref_res, lut_res;
 //   scene 240 B; per light 6 floats (position, colour); albedo, normal, arm, position (w*h*8 B each);
 //   dir shadow (dir_res^2 floats); cube shadows (n_lights*6*cube_res^2 floats); env cube (6*env_res^2*8 B)
+//   optional trailer: int32 n_draws; per draw: int32 n_verts, n_tris; positions (3 f32 per vertex), texcoords (2),
+//   normals (3), tangents (3); indices (3 u32 per triangle); model (16 f32); three RGBA8 images, each int32 w, h + bytes.
+//   With draws the frame is rendered from them (CreateMesh / CreateMaterial / DrawModel): nothing is uploaded.
 // output file: colour, threshold (w*h*8 B each), ldr (w*h*4 B), irradiance cube, prefilter mip 0, LUT
 #include <cstdio>
 #include <cstdlib>
@@ -38,6 +41,28 @@ int main(int argc, char **argv)
     read_exact(in, cubes.data(), cubes.size() * 4);
     std::vector<uint16_t> env((size_t)6 * env_res * env_res * 4);
     read_exact(in, env.data(), env.size() * 2);
+    struct Draw {
+        std::vector<float> pos, uv, nrm, tan; std::vector<uint32_t> idx; float model[16];
+        std::vector<uint8_t> tex[3]; int32_t tw[3], th[3]; int32_t n_verts, n_tris;
+    };
+    std::vector<Draw> draws;
+    int32_t n_draws = 0;
+    if (fread(&n_draws, 4, 1, in) == 1 && n_draws > 0) {
+        draws.resize(n_draws);
+        for (Draw &d : draws) {
+            read_exact(in, &d.n_verts, 4); read_exact(in, &d.n_tris, 4);
+            d.pos.resize((size_t)d.n_verts * 3); d.uv.resize((size_t)d.n_verts * 2); d.nrm.resize((size_t)d.n_verts * 3); d.tan.resize((size_t)d.n_verts * 3);
+            d.idx.resize((size_t)d.n_tris * 3);
+            read_exact(in, d.pos.data(), d.pos.size() * 4); read_exact(in, d.uv.data(), d.uv.size() * 4);
+            read_exact(in, d.nrm.data(), d.nrm.size() * 4); read_exact(in, d.tan.data(), d.tan.size() * 4);
+            read_exact(in, d.idx.data(), d.idx.size() * 4); read_exact(in, d.model, 64);
+            for (int k = 0; k < 3; k++) {
+                read_exact(in, &d.tw[k], 4); read_exact(in, &d.th[k], 4);
+                d.tex[k].resize((size_t)d.tw[k] * d.th[k] * 4);
+                read_exact(in, d.tex[k].data(), d.tex[k].size());
+            }
+        }
+    }
     fclose(in);
 
     try {
@@ -52,14 +77,28 @@ int main(int argc, char **argv)
         r.CreatePrefilteredCubemap();
         r.CreateBRDFLUTTexture();
         r.Lights = lights;
+        std::vector<int32_t> meshes, materials;
+        for (const Draw &d : draws) {  // Mesh.cs / Material.cs
+            meshes.push_back(r.CreateMesh(d.pos.data(), d.n_verts, d.idx.data(), d.n_tris));
+            r.SetMeshAttributes(meshes.back(), d.uv.data(), d.nrm.data(), d.tan.data());
+            materials.push_back(r.CreateMaterial(d.tex[0].data(), d.tw[0], d.th[0], d.tex[1].data(), d.tw[1], d.th[1], d.tex[2].data(), d.tw[2], d.th[2]));
+        }
         int32_t frame = 0;
         for (int k = 0; k < 2; k++) {
             frame = r.CurrentFrame();
             r.BeginFrame();
             r.UpdateSceneInfo(scene);
-            r.UploadGBuffer(albedo.data(), normal.data(), arm.data(), position.data());
-            r.UploadDirectionalShadowMap(dir.data());
-            for (int i = 0; i < nl; i++) r.UploadPointShadowMap(i, cubes.data() + (size_t)i * 6 * cube_res * cube_res);
+            if (draws.empty()) {
+                r.UploadGBuffer(albedo.data(), normal.data(), arm.data(), position.data());
+                r.UploadDirectionalShadowMap(dir.data());
+                for (int i = 0; i < nl; i++) r.UploadPointShadowMap(i, cubes.data() + (size_t)i * 6 * cube_res * cube_res);
+            } else {
+                for (size_t i = 0; i < draws.size(); i++) {  // Program.OnRender: renderer.DrawModel(model, transform)
+                    float m[16];
+                    for (int j = 0; j < 16; j++) m[j] = draws[i].model[j];
+                    r.DrawModel(meshes[i], m, materials[i]);
+                }
+            }
             r.EndFrame();
         }
         r.WaitIdle();

@@ -783,3 +783,55 @@ def test_large_triangles_are_shared_by_the_wave(gpu, oracle):
     want_dir = oracle.dir_shadow_map(sd, ls, 256)
     got_dir = P.dir_shadow_map(_device_draws(sd, gpu), ls, 256, gpu)
     assert np.array_equal(got_dir.cpu().numpy().view(np.uint32), want_dir.view(np.uint32))
+
+
+def test_cpp_host_program_renders_from_draw_calls(gpu, oracle, tmp_path):
+    """The C++ mirror driven like the reference's render loop with models only: CreateMesh, CreateMaterial,
+    DrawModel between BeginFrame and EndFrame; its frame equals the oracle's geometry + shadow + shading chain."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "renderer_roundtrip")
+    assert os.path.exists(exe), "tests/cpp/renderer_roundtrip is not built: run __graft_entry__.build()"
+    w, h, nl, dres, cres, eres, ires, pres, lres = 120, 64, 2, 64, 16, 16, 4, 8, 16
+    f = synth.make_frame(53, w, h, nl, cres, dres, irr_res=ires, pref_res=pres, lut_res=lres)
+    f.scene = _camera_scene((2.0, 1.6, -4.0), aspect=w / h)
+    env = synth.make_env_cube(np.random.default_rng(8), eres)
+    draws = _gpass_scene(w, h)
+    inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(inp, "wb") as fh:
+        fh.write(np.array([w, h, nl, dres, cres, eres, ires, pres, lres], dtype=np.int32).tobytes())
+        fh.write(f.scene.tobytes())
+        for l in f.lights:
+            fh.write(np.asarray(l["position"][:3], dtype=np.float32).tobytes())
+            fh.write(np.asarray(l["color"][:3], dtype=np.float32).tobytes())
+        for a in (f.albedo, f.normal, f.arm, f.position, f.dir_shadow, f.cube_shadow, env):
+            fh.write(np.ascontiguousarray(a).tobytes())
+        fh.write(np.int32(len(draws)).tobytes())
+        for d in draws:
+            fh.write(np.array([len(d["positions"]), len(d["triangles"])], dtype=np.int32).tobytes())
+            for k in ("positions", "texcoords", "normals", "tangents"):
+                fh.write(np.ascontiguousarray(d[k], dtype=np.float32).tobytes())
+            fh.write(np.ascontiguousarray(d["triangles"], dtype=np.uint32).tobytes())
+            fh.write(np.ascontiguousarray(d["model"], dtype=np.float32).tobytes())
+            for k in ("albedo", "normal", "arm"):
+                fh.write(np.array([d[k].shape[1], d[k].shape[0]], dtype=np.int32).tobytes())
+                fh.write(np.ascontiguousarray(d[k], dtype=np.uint8).tobytes())
+    proc = subprocess.run([exe, str(inp), str(outp)], capture_output=True, text=True, timeout=100)
+    assert proc.returncode == 0, proc.stderr
+    raw = np.fromfile(outp, dtype=np.uint8)
+    sizes = [w * h * 8, w * h * 8, w * h * 4, 6 * ires * ires * 8, 6 * pres * pres * 8, lres * lres * 4]
+    parts = np.split(raw, np.cumsum(sizes)[:-1])
+    color, thr = (p.view(np.uint16).reshape(h, w, 4) for p in parts[:2])
+    ldr = parts[2].reshape(h, w, 4)
+    f.irradiance = parts[3].view(np.uint16).reshape(6, ires, ires, 4)
+    f.prefilter = parts[4].view(np.uint16).reshape(6, pres, pres, 4)
+    f.brdf_lut = parts[5].view(np.uint16).reshape(lres, lres, 2)
+    # vkr::Light::ToInfo gives the lights the reference's volume radius; the shading only reads position and colour
+    f.albedo, f.normal, f.arm, f.position = oracle.gbuffer(draws, f.scene, w, h)
+    sd = [(d["positions"], d["triangles"], d["model"]) for d in draws]
+    f.cube_shadow = oracle.point_shadow_maps(sd, f.lights, cres)
+    f.dir_shadow = oracle.dir_shadow_map(sd, f.scene["light_space_matrix"], dres)
+    want = oracle.frame_chain(f)
+    assert_bits_equal(color, want["color"], "colour")
+    assert_bits_equal(thr, want["threshold"], "threshold")
+    assert np.abs(ldr.astype(np.int32) - want["ldr"].astype(np.int32)).max() <= 1
