@@ -372,6 +372,11 @@ def main() -> None:
     if world == 1 and not args.no_coverage:
         out["light_volume_coverage"] = time_coverage(f, dev_frame, renderer, device)
         out["shadow_pass"] = time_shadow_pass(f, dev_frame, device)
+        sp, cv = out["shadow_pass"], out["light_volume_coverage"]["reference_radii"]
+        whole = sp["point_shadow_ms"] + sp["dir_shadow_ms"] + sp["geometry_pass_ms"] + cv["coverage_ms"] + ms_per_step
+        out["frame_from_meshes"] = {"ms": round(whole, 3), "Mpixels/s": round(px / (whole * 1e-3) / 1e6, 1),
+                                    "note": "shadow passes + geometry pass + light-volume coverage + the timed step: a frame in which "
+                                            "every light moves and nothing but meshes, materials, lights and the camera is given"}
     if not args.no_ibl:
         out["ibl_precompute"] = time_ibl(device)
     if world == 1 and args.cpu_rows > 0:
