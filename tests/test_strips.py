@@ -35,6 +35,15 @@ class OracleBackend:
         self._bits(color)[...] = c
         self._bits(thr)[...] = t
 
+    def frame_from_draws(self, frame, draws, shadow_res, dir_res, frame_rows, row0):
+        import dataclasses
+        from tests import oracle
+        a, n, m, p = oracle.gbuffer(draws, frame.scene, frame.width, frame.height, frame_rows, row0)
+        sd = [(d["positions"], d["triangles"], d["model"]) for d in draws]
+        return dataclasses.replace(frame, albedo=a, normal=n, arm=m, position=p,
+                                   cube_shadow=oracle.point_shadow_maps(sd, frame.lights, shadow_res),
+                                   dir_shadow=oracle.dir_shadow_map(sd, frame.scene["light_space_matrix"], dir_res))
+
     def with_coverage(self, frame, volume_mesh, frame_rows, row0):
         from tests import oracle
         verts, tris = volume_mesh
@@ -120,6 +129,54 @@ def test_strips_with_light_volume_coverage(tmp_path, oracle):
     want = oracle.postprocess(color, b2)
     out_path = str(tmp_path / "ldr.npy")
     mp.spawn(_worker, args=(3, _free_port(), out_path, True), nprocs=3, join=True)
+    assert np.array_equal(np.load(out_path), want)
+
+
+def _scene_draws():
+    slab = synth.make_scene_mesh(10)
+    uv, nrm, tan = synth.mesh_attributes(*slab, uv_scale=0.25)
+    alb, nmap, arm = synth.make_material(np.random.default_rng(4), 16)
+    return [dict(positions=slab[0], texcoords=uv, normals=nrm, tangents=tan, triangles=slab[1], model=np.eye(4),
+                 albedo=alb, normal=nmap, arm=arm)]
+
+
+def _draws_frame():
+    f = _frame()
+    f.scene = f.scene.copy()
+    f.scene["camera_view"] = synth.look_at((2.0, 1.6, -4.0), (0, 0, 0), (0, 1, 0)).astype(np.float32).ravel()
+    f.scene["camera_projection"] = synth.perspective(60.0, W / H, 0.1, 100.0).astype(np.float32).ravel()
+    f.scene["camera_position"] = (2.0, 1.6, -4.0)
+    return f
+
+
+def _draws_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        f = _draws_frame()
+        plan = StripPlan.make(rank, world, H)
+        r = StripRenderer(plan, W, backend=OracleBackend())
+        r.render_draws(f.rows(plan.row0, plan.row0 + plan.rows), _scene_draws(), 16, 32)
+        parts = r.gather(0)
+        if rank == 0:
+            np.save(out_path, torch.cat(parts, 0).numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_strips_render_a_frame_from_draw_calls(tmp_path, oracle):
+    """Every rank rasterises its own rows of the G-buffer (row0 of total_rows enters the projection) and all the
+    shadow maps; the assembled image is the single-device frame rendered from the same draw calls."""
+    f = _draws_frame()
+    draws = _scene_draws()
+    f.albedo, f.normal, f.arm, f.position = oracle.gbuffer(draws, f.scene, W, H)
+    sd = [(d["positions"], d["triangles"], d["model"]) for d in draws]
+    f.cube_shadow = oracle.point_shadow_maps(sd, f.lights, 16)
+    f.dir_shadow = oracle.dir_shadow_map(sd, f.scene["light_space_matrix"], 32)
+    want = oracle.frame_chain(f)["ldr"]
+    assert (f.albedo[..., 3] != 0).mean() > 0.2
+    out_path = str(tmp_path / "ldr.npy")
+    mp.spawn(_draws_worker, args=(3, _free_port(), out_path), nprocs=3, join=True)
     assert np.array_equal(np.load(out_path), want)
 
 
