@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void gpass_visibility_kernel(const GpassParams
         raster_setup(clip, tr);
         int qy0, qy1, rx0, rx1, ry0, ry1;
         // BACK faces (D > 0) and degenerate triangles are culled
-        have = tr.D < 0.0 && shadow_bbox(clip, p.width, bx0, qy0, bx1, qy1) && shadow_bbox(clip, p.frame_rows, rx0, ry0, rx1, ry1);
+        have = !clip_reject(clip) && tr.D < 0.0 && shadow_bbox(clip, p.width, bx0, qy0, bx1, qy1) && shadow_bbox(clip, p.frame_rows, rx0, ry0, rx1, ry1);
         if (have) {
             by0 = max(ry0 - p.row0, 0); by1 = min(ry1 - p.row0, p.rows - 1);
             have = by0 <= by1;

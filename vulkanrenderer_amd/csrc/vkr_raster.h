@@ -86,6 +86,21 @@ VKR_DEV bool shadow_bbox(const float (&c)[3][4], int res, int &bx0, int &by0, in
     return true;
 }
 
+// True when the triangle lies entirely outside one plane of the clip volume (-w <= x,y <= w, z >= 0):
+// nothing of it can be covered, and the binary64 setup can be skipped.  Exact comparisons on the
+// binary32 clip coordinates, so this only ever drops triangles the full test would drop as well.
+VKR_DEV bool clip_reject(const float (&c)[3][4])
+{
+    bool xp = true, xn = true, yp = true, yn = true, zn = true;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        xp = xp && c[k][0] > c[k][3]; xn = xn && c[k][0] < -c[k][3];
+        yp = yp && c[k][1] > c[k][3]; yn = yn && c[k][1] < -c[k][3];
+        zn = zn && c[k][2] < 0.0f;
+    }
+    return xp || xn || yp || yn || zn;
+}
+
 VKR_DEV float readlane_f(float x, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src)); }
 
 static constexpr int RASTER_BIG = 128;  // bounding boxes with more samples than this are walked by the whole wave (32..128 measured equal, 1024 40 % slower)

@@ -61,7 +61,7 @@ template <bool POINT>
 VKR_DEV void shadow_raster(bool valid, const float (&clip)[3][4], const float (&world)[3][4], const float *light_pos, float inv_far, int res, bool tiled, float *img)
 {
     int bx0 = 0, by0 = 0, bx1 = -1, by1 = -1;
-    bool have = valid;
+    bool have = valid && !clip_reject(clip);
     if (have) {
         STri t;
         raster_setup(clip, t);
