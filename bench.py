@@ -165,7 +165,7 @@ def time_shadow_pass(f, dev_frame, device) -> dict:
     mesh: a closed slab under the height field, 129^2 grid.  Not part of a step (the benchmark frame keeps its
     synthetic maps resident); what a frame with moving lights would add."""
     import torch
-    from vulkanrenderer_amd import passes as P, synth
+    from vulkanrenderer_amd import _lib, passes as P, synth
     verts, tris = synth.make_scene_mesh(128)
     draws = [(torch.from_numpy(verts).to(device), torch.from_numpy(tris.astype(np.int32)).to(device), np.eye(4))]
     res, dres, nl = f.cube_shadow.shape[-1], f.dir_shadow.shape[-1], len(f.lights)
@@ -187,10 +187,12 @@ def time_shadow_pass(f, dev_frame, device) -> dict:
     scene = f.scene.copy()
     scene["camera_projection"] = synth.perspective(60.0, f.width / f.height, 0.1, 100.0).astype(np.float32).ravel()
     ga = P.gbuffer(gdraws, scene, f.width, f.height, device)[0]
+    env = P.tile_env_cube(P.to_device_f16(synth.make_env_cube(np.random.default_rng(SEED + 10), 2048), device))
     return {"point_shadow_ms": round(timed(lambda: P.point_shadow_maps(draws, dev_frame.lights, nl, res)), 4),
             "dir_shadow_ms": round(timed(lambda: P.dir_shadow_map(draws, f.scene["light_space_matrix"], dres, device)), 4),
             "geometry_pass_ms": round(timed(lambda: P.gbuffer(gdraws, scene, f.width, f.height, device)), 4),
             "geometry_pass_covered_fraction": round(float((ga[..., 3] != 0).float().mean()), 4),
+            "skybox_ms": round(timed(lambda: P.skybox(env, scene, f.width, f.height, env_layout=_lib.ENV_LAYOUT_TILED_4X4)), 4),
             "config": f"{nl} lights x 6 x {res}^2 D32F (written as 8x4 tiles) + {dres}^2 directional map; mesh {len(verts)} vertices, {len(tris)} triangles"}
 
 
@@ -373,9 +375,9 @@ def main() -> None:
         out["light_volume_coverage"] = time_coverage(f, dev_frame, renderer, device)
         out["shadow_pass"] = time_shadow_pass(f, dev_frame, device)
         sp, cv = out["shadow_pass"], out["light_volume_coverage"]["reference_radii"]
-        whole = sp["point_shadow_ms"] + sp["dir_shadow_ms"] + sp["geometry_pass_ms"] + cv["coverage_ms"] + ms_per_step
+        whole = sp["point_shadow_ms"] + sp["dir_shadow_ms"] + sp["geometry_pass_ms"] + sp["skybox_ms"] + cv["coverage_ms"] + ms_per_step
         out["frame_from_meshes"] = {"ms": round(whole, 3), "Mpixels/s": round(px / (whole * 1e-3) / 1e6, 1),
-                                    "note": "shadow passes + geometry pass + light-volume coverage + the timed step: a frame in which "
+                                    "note": "shadow passes + geometry pass + skybox + light-volume coverage + the timed step: a frame in which "
                                             "every light moves and nothing but meshes, materials, lights and the camera is given"}
     if not args.no_ibl:
         out["ibl_precompute"] = time_ibl(device)

@@ -205,6 +205,12 @@ typedef struct VkrGpassArgs {
 VKR_EXPORT int64_t vkr_gbuffer_workspace_bytes(int32_t width, int32_t rows, int32_t n_draws);
 VKR_EXPORT int32_t vkr_gbuffer(const VkrGpassArgs *args, void *stream);
 
+/* Replaces the skybox draw that opens the composition pass (VulkanRenderer.cs:436-443; cubemap.vert, skybox.frag):
+ * colour = texture(skybox cube, view ray of the pixel), alpha 1.  The result is the `background` of VkrShadeArgs,
+ * kept where the composition draw discards.  Assumes the reference's symmetric perspective (Camera.cs:30-35). */
+VKR_EXPORT int32_t vkr_skybox(const void *env, int32_t env_n, int32_t env_layout, const VkrSceneInfo *scene,
+                              int32_t width, int32_t rows, int32_t frame_rows, int32_t row0, void *out_rgba16f, void *stream);
+
 /* Re-lays `n_faces` D32F faces of `res`^2 texels from VKR_CUBE_LAYOUT_LINEAR to
  * VKR_CUBE_LAYOUT_TILED_8X4 (res % 8 == 0; src and dst must not overlap).  No counterpart in the
  * reference, whose depth images are written tiled by the rasteriser. */
@@ -325,6 +331,9 @@ VKR_EXPORT int32_t vkr_draw_model(vkr_ctx *ctx, int32_t mesh, int32_t material, 
 
 /* Images of passes the frame does not render itself (see vkr_draw_model), for the current frame. */
 VKR_EXPORT int32_t vkr_upload_gbuffer(vkr_ctx *ctx, const void *albedo, const void *normal, const void *arm, const void *position);
+/* An image in place of the skybox draw (VulkanRenderer.cs:436-443) for the current frame.  Without one, EndFrame
+ * draws the skybox from the environment cube when there is one (vkr_create_skybox_cubemap / vkr_upload_env_cube);
+ * with neither, texels the composition draw discards stay (0,0,0,1). */
 VKR_EXPORT int32_t vkr_upload_background(vkr_ctx *ctx, const void *rgba16f_or_null);
 VKR_EXPORT int32_t vkr_upload_dir_shadow(vkr_ctx *ctx, const float *depth);
 VKR_EXPORT int32_t vkr_upload_point_shadow(vkr_ctx *ctx, int32_t light, const float *depth_cube);

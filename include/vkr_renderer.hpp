@@ -112,7 +112,7 @@ public:
     void Resize(int32_t width, int32_t height) { check(vkr_resize(ctx_, width, height)); }  // RecreateSwapchain
     int32_t CurrentFrame() const { return vkr_current_frame(ctx_); }
 
-    // results of the passes outside this path (geometry, shadow maps, skybox)
+    // for a caller that renders the geometry pass, the shadow maps or the skybox itself: the images of those passes
     void UploadGBuffer(const void *albedo, const void *normal, const void *arm, const void *position)
     {
         check(vkr_upload_gbuffer(ctx_, albedo, normal, arm, position));

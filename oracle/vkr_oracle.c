@@ -1426,3 +1426,34 @@ ORC_API void orc_gbuffer(const orc_gpass_args *a)
         }
     free(vis);
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Skybox draw of the composition pass (VulkanRenderer.cs:436-443; cubemap.vert, skybox.frag): a unit
+ * cube around the camera, view matrix reduced to its rotation, colour = texture(skybox, position
+ * on the cube).  The cube lookup depends only on the direction of that position, which is the
+ * pixel's view ray: ray_view = (xn / proj[0][0], yn / proj[1][1], -1) for the reference's
+ * symmetric perspective (Camera.cs:30-35), turned into world space by the transposed rotation
+ * of the view matrix.  Written where the composition draw later discards (alpha == 0). */
+typedef struct {
+    const uint16_t *env; int32_t env_n;     /* RGBA16F cube, row-major faces */
+    const orc_scene_info *scene;
+    int32_t width, rows, frame_rows, row0;
+    uint16_t *out;                          /* RGBA16F rows * width */
+} orc_skybox_args;
+
+ORC_API void orc_skybox(const orc_skybox_args *a)
+{
+    const float *V = a->scene->camera_view, *P = a->scene->camera_proj;
+    const float sx = 2.0f / (float)a->width, sy = 2.0f / (float)a->frame_rows;
+    const float ipx = rcpf_(P[0]), ipy = rcpf_(P[5]);
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < a->rows; y++)
+        for (int x = 0; x < a->width; x++) {
+            const float xn = fmaf((float)x + 0.5f, sx, -1.0f), yn = fmaf((float)(a->row0 + y) + 0.5f, sy, -1.0f);
+            const float vx = xn * ipx, vy = yn * ipy, vz = -1.0f;
+            const v3 d = v3_(fmaf(vz, V[2], fmaf(vy, V[1], vx * V[0])), fmaf(vz, V[6], fmaf(vy, V[5], vx * V[4])), fmaf(vz, V[10], fmaf(vy, V[9], vx * V[8])));
+            const v3 c = texcube_rgb_linear(a->env, a->env_n, d);
+            uint16_t *o = a->out + ((size_t)y * a->width + x) * 4;
+            o[0] = f2h(c.x); o[1] = f2h(c.y); o[2] = f2h(c.z); o[3] = 0x3C00;
+        }
+}

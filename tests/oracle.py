@@ -69,6 +69,11 @@ class GpassArgs(C.Structure):
                 ("albedo", C.c_void_p), ("normal", C.c_void_p), ("arm", C.c_void_p), ("position", C.c_void_p)]
 
 
+class SkyboxArgs(C.Structure):
+    _fields_ = [("env", C.c_void_p), ("env_n", C.c_int32), ("scene", C.c_void_p),
+                ("width", C.c_int32), ("rows", C.c_int32), ("frame_rows", C.c_int32), ("row0", C.c_int32), ("out", C.c_void_p)]
+
+
 def build() -> None:
     subprocess.run(["make", "-C", ORACLE_DIR, "-s"], check=True)
 
@@ -257,6 +262,18 @@ def gpass_fragment(d: dict, uv, tbn):
     alb, wn, arm = np.empty(4, np.float32), np.empty(3, np.float32), np.empty(4, np.float32)
     load().orc_gpass_fragment(C.byref(arr[0]), C.c_float(uv[0]), C.c_float(uv[1]), _p(tbn), _p(alb), _p(wn), _p(arm))
     return alb, wn, arm
+
+
+def skybox(env: np.ndarray, scene: np.ndarray, width: int, rows: int, frame_rows: int | None = None, row0: int = 0) -> np.ndarray:
+    """The skybox draw (cubemap.vert / skybox.frag): RGBA16F bits [rows, width, 4]."""
+    env = np.ascontiguousarray(env, dtype=np.uint16)
+    scene = np.ascontiguousarray(scene).reshape(1)
+    out = np.empty((rows, width, 4), dtype=np.uint16)
+    a = SkyboxArgs()
+    a.env, a.env_n, a.scene = _p(env), env.shape[1], _p(scene)
+    a.width, a.rows, a.frame_rows, a.row0, a.out = width, rows, rows if frame_rows is None else frame_rows, row0, _p(out)
+    load().orc_skybox(C.byref(a))
+    return out
 
 
 def shade(f, background: np.ndarray | None = None, rows: tuple[int, int] | None = None, coverage: np.ndarray | None = None):

@@ -113,3 +113,22 @@ def test_geometry_pass_shaders(oracle):
         assert np.allclose(wn, g["frag_normal"][i][:3], atol=2e-6), i
         assert np.allclose(arm, g["frag_arm"][i], atol=2e-6), i
         assert g["frag_normal"][i][3] == 1.0
+
+
+def test_skybox_shaders(oracle):
+    """cubemap.vert.spv + skybox.frag.spv: the recorded points of the unit cube project (by the reference's
+    vertex shader) onto the centres of the recorded pixels, and the reference's fragment shader gives there
+    the colour the oracle's skybox pass gives that pixel.  The cube lookup is continuous in direction, so the
+    rounding of the ray moves the colour by far less than the tolerance."""
+    g = np.load(os.path.join(GOLDEN, "skybox.npz"))
+    w, h = int(g["width"]), int(g["height"])
+    for k in range(len(g["scenes"])):
+        px, clip = g["pixels"][k], g["gl_position"][k]
+        assert (clip[:, 3] > 0).all()
+        ndc = clip[:, :2] / clip[:, 3:]
+        centre = np.stack([(2 * px[:, 0] + 1) / w - 1, (2 * px[:, 1] + 1) / h - 1], -1)
+        assert np.abs(ndc - centre).max() < 1e-5          # a 48-pixel row: a pixel is 4e-2 wide in these units
+        sky = oracle.f16_to_f32(oracle.skybox(g["env"], g["scenes"][k], w, h))
+        got = sky[px[:, 1], px[:, 0]]
+        assert close(got, g["colour"][k]).all(), (k, np.abs(got - g["colour"][k]).max())
+        assert (got[:, 3] == 1.0).all()

@@ -213,7 +213,7 @@ def test_renderer_end_frame_matches_oracle_chain(gpu, oracle):
         f.irradiance = r.Read(_lib.TARGET_IRRADIANCE)
         f.prefilter = r.Read(_lib.TARGET_PREFILTER, mip=0)
         f.brdf_lut = r.Read(_lib.TARGET_BRDF_LUT)
-        want = oracle.frame_chain(f)
+        want = oracle.frame_chain(f, oracle.skybox(env, f.scene, w, h))  # EndFrame opens with the skybox draw
         for _ in range(3):  # cycles through both frames in flight
             frame = r.CurrentFrame
             r.UpdateSceneInfo(f.scene)
@@ -325,7 +325,7 @@ def test_cpp_host_program_matches_oracle(gpu, oracle, tmp_path):
     assert_bits_equal(f.irradiance, oracle.irradiance(env, ires, 0), "irradiance")
     assert_bits_equal(f.prefilter, oracle.prefilter(env, pres, 0.0), "prefilter")
     assert_bits_equal(f.brdf_lut, oracle.brdf_lut(lres), "BRDF LUT")
-    want = oracle.frame_chain(f)
+    want = oracle.frame_chain(f, oracle.skybox(env, f.scene, w, h))
     assert_bits_equal(color, want["color"], "colour")
     assert_bits_equal(thr, want["threshold"], "threshold")
     assert np.abs(ldr.astype(np.int32) - want["ldr"].astype(np.int32)).max() <= 1
@@ -498,7 +498,8 @@ def test_renderer_with_light_volume_mesh(gpu, oracle):
     masks = oracle.light_coverage(f.scene, f.lights, verts, tris, w, h)
     with HipRenderer(w, h, max_lights=8, dir_shadow_res=64, point_shadow_res=16, env_res=16,
                      irradiance_res=8, prefilter_res=16, prefilter_mips=1, brdf_lut_res=32) as r:
-        r.UploadEnvironmentCubemap(synth.make_env_cube(np.random.default_rng(2), 16))
+        env = synth.make_env_cube(np.random.default_rng(2), 16)
+        r.UploadEnvironmentCubemap(env)
         r.CreateIrradianceCubemap(); r.CreatePrefilteredCubemap(); r.CreateBRDFLUTTexture()
         f.irradiance = r.Read(_lib.TARGET_IRRADIANCE)
         f.prefilter = r.Read(_lib.TARGET_PREFILTER, mip=0)
@@ -517,7 +518,7 @@ def test_renderer_with_light_volume_mesh(gpu, oracle):
         r.SetLightInfos(f.lights, _lib.COVERAGE_MESH)
         r.BeginFrame()
         r._call(r._lib.vkr_end_frame)
-        want_c, want_t = oracle.shade(f, coverage=masks)
+        want_c, want_t = oracle.shade(f, oracle.skybox(env, f.scene, w, h), coverage=masks)
         assert_bits_equal(r.Read(_lib.TARGET_COLOR, 0), want_c, "colour")
         assert_bits_equal(r.Read(_lib.TARGET_THRESHOLD, 0), want_t, "threshold")
 
@@ -612,7 +613,8 @@ def test_renderer_draw_calls_make_the_shadow_maps(gpu, oracle):
     f.dir_shadow = oracle.dir_shadow_map(draws, f.scene["light_space_matrix"], 64)
     with HipRenderer(w, h, max_lights=4, dir_shadow_res=64, point_shadow_res=32, env_res=16,
                      irradiance_res=8, prefilter_res=16, prefilter_mips=1, brdf_lut_res=32) as r:
-        r.UploadEnvironmentCubemap(synth.make_env_cube(np.random.default_rng(2), 16))
+        env = synth.make_env_cube(np.random.default_rng(2), 16)
+        r.UploadEnvironmentCubemap(env)
         r.CreateIrradianceCubemap(); r.CreatePrefilteredCubemap(); r.CreateBRDFLUTTexture()
         f.irradiance = r.Read(_lib.TARGET_IRRADIANCE)
         f.prefilter = r.Read(_lib.TARGET_PREFILTER, mip=0)
@@ -620,7 +622,7 @@ def test_renderer_draw_calls_make_the_shadow_maps(gpu, oracle):
         m_slab, m_ball = r.CreateMesh(*slab), r.CreateMesh(*ball)
         with pytest.raises(_lib.VkrError):
             r.DrawModel(m_slab, np.eye(4))          # outside a frame
-        want_c, want_t = oracle.shade(f)
+        want_c, want_t = oracle.shade(f, oracle.skybox(env, f.scene, w, h))
         for _ in range(2):                           # both frames in flight
             frame = r.CurrentFrame
             r.UpdateSceneInfo(f.scene)
@@ -721,7 +723,8 @@ def test_renderer_renders_a_frame_from_draw_calls_only(gpu, oracle):
     sphere = synth.make_sphere_mesh()
     with HipRenderer(w, h, max_lights=4, dir_shadow_res=64, point_shadow_res=32, env_res=16,
                      irradiance_res=8, prefilter_res=16, prefilter_mips=1, brdf_lut_res=32) as r:
-        r.UploadEnvironmentCubemap(synth.make_env_cube(np.random.default_rng(2), 16))
+        env = synth.make_env_cube(np.random.default_rng(2), 16)
+        r.UploadEnvironmentCubemap(env)
         r.CreateIrradianceCubemap(); r.CreatePrefilteredCubemap(); r.CreateBRDFLUTTexture()
         f.irradiance = r.Read(_lib.TARGET_IRRADIANCE)
         f.prefilter = r.Read(_lib.TARGET_PREFILTER, mip=0)
@@ -737,7 +740,8 @@ def test_renderer_renders_a_frame_from_draw_calls_only(gpu, oracle):
         f.cube_shadow = oracle.point_shadow_maps(sd, f.lights, 32)
         f.dir_shadow = oracle.dir_shadow_map(sd, f.scene["light_space_matrix"], 64)
         masks = oracle.light_coverage(f.scene, f.lights, sphere[0], sphere[1], w, h)
-        color, thr = oracle.shade(f, coverage=masks)
+        sky = oracle.skybox(env, f.scene, w, h)
+        color, thr = oracle.shade(f, sky, coverage=masks)
         b2 = oracle.bloom_blur(oracle.bloom_blur(thr, True, oracle.WRAP_REPEAT), False, oracle.WRAP_CLAMP)
         want_ldr = oracle.postprocess(color, b2)
         for _ in range(2):
@@ -753,6 +757,8 @@ def test_renderer_renders_a_frame_from_draw_calls_only(gpu, oracle):
             ldr = r.Read(_lib.TARGET_LDR, frame)
             assert np.abs(ldr.astype(np.int32) - want_ldr.astype(np.int32)).max() <= 1
         assert (color[..., :3] != 0).any()
+        bare = f.albedo[..., 3] == 0  # texels no triangle covers show the sky
+        assert bare.any() and not bare.all() and np.array_equal(color[bare], sky[bare])
 
 
 def test_large_triangles_are_shared_by_the_wave(gpu, oracle):
@@ -831,7 +837,42 @@ def test_cpp_host_program_renders_from_draw_calls(gpu, oracle, tmp_path):
     sd = [(d["positions"], d["triangles"], d["model"]) for d in draws]
     f.cube_shadow = oracle.point_shadow_maps(sd, f.lights, cres)
     f.dir_shadow = oracle.dir_shadow_map(sd, f.scene["light_space_matrix"], dres)
-    want = oracle.frame_chain(f)
+    want = oracle.frame_chain(f, oracle.skybox(env, f.scene, w, h))
     assert_bits_equal(color, want["color"], "colour")
     assert_bits_equal(thr, want["threshold"], "threshold")
     assert np.abs(ldr.astype(np.int32) - want["ldr"].astype(np.int32)).max() <= 1
+
+
+@pytest.mark.parametrize("w,h,row0,frame_rows", [(160, 90, 0, 90), (131, 37, 19, 77), (64, 1, 63, 64)])
+def test_skybox_bit_exact(gpu, oracle, w, h, row0, frame_rows):
+    """The skybox draw from a row-major and from a 4x4-tiled environment cube, whole frames and strips, for
+    cameras that see face edges and corners of the cube; and as the background of the composition pass."""
+    torch, P = _torch(), _passes()
+    n = 32
+    env = synth.make_env_cube(np.random.default_rng(91), n)
+    dev_env = P.to_device_f16(env, gpu)
+    tiled = P.tile_env_cube(dev_env)
+    for cam, target in (((2.0, 1.6, -4.0), (0.0, 0.0, 0.0)), ((0.0, 0.0, 0.0), (1.0, 1.0, 1.0)), ((1.0, 5.0, 1.0), (1.0, 0.0, 1.001))):
+        scene = _camera_scene(cam, target, aspect=w / frame_rows)
+        want = oracle.skybox(env, scene, w, h, frame_rows, row0)
+        got = P.skybox(dev_env, scene, w, h, frame_rows, row0)
+        assert_bits_equal(P.f16_bits(got), want, f"skybox, camera {cam}")
+        got_t = P.skybox(tiled, scene, w, h, frame_rows, row0, env_layout=_lib.ENV_LAYOUT_TILED_4X4)
+        assert_bits_equal(P.f16_bits(got_t), want, f"skybox from the tiled cube, camera {cam}")
+        assert (want[..., 3] == 0x3C00).all() and len(np.unique(want[..., 0])) > 1
+    if row0 == 0 and h == frame_rows:
+        f = synth.make_frame(92, w, h, 2, 16, 64, irr_res=8, pref_res=16, lut_res=32)
+        f.scene = _camera_scene((2.0, 1.6, -4.0), aspect=w / h)
+        sky = oracle.skybox(env, f.scene, w, h)
+        want_c, want_t = oracle.shade(f, background=sky)
+        d = P.DeviceFrame.upload(f, gpu)
+        d.background = P.skybox(tiled, f.scene, w, h, env_layout=_lib.ENV_LAYOUT_TILED_4X4)
+        color = torch.empty((h, w, 4), dtype=torch.float16, device=gpu)
+        thr = torch.empty_like(color)
+        P.shade(d, color, thr)
+        assert_bits_equal(P.f16_bits(color), want_c, "colour over the sky")
+        assert_bits_equal(P.f16_bits(thr), want_t, "threshold over the sky")
+    bad = _camera_scene((0.0, 0.0, 1.0))
+    bad["camera_projection"] = np.zeros(16, dtype=np.float32)
+    with pytest.raises(_lib.VkrError):
+        P.skybox(dev_env, bad, w, h, frame_rows, row0)

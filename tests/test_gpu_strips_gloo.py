@@ -145,6 +145,10 @@ def _draws_scene():
                  albedo=alb, normal=nmap, arm=arm)]
 
 
+def _sky_cube():
+    return synth.make_env_cube(np.random.default_rng(12), 16)
+
+
 def _draws_frame():
     f = _frame()
     f.scene = f.scene.copy()
@@ -170,7 +174,7 @@ def _to_device(draws, dev):
 def _draws_worker(rank, world, port, out_path):
     import torch
     import torch.distributed as dist
-    from vulkanrenderer_amd import passes as P
+    from vulkanrenderer_amd import _lib, passes as P
     from vulkanrenderer_amd.strips import StripPlan, StripRenderer
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -180,7 +184,8 @@ def _draws_worker(rank, world, port, out_path):
         plan = StripPlan.make(rank, world, H)
         r = StripRenderer(plan, W, device=dev)
         frame = P.DeviceFrame.upload(f.rows(plan.row0, plan.row0 + plan.rows), dev)
-        r.render_draws(frame, _to_device(_draws_scene(), dev), 32, 64)
+        env = P.tile_env_cube(P.to_device_f16(_sky_cube(), dev))
+        r.render_draws(frame, _to_device(_draws_scene(), dev), 32, 64, env=(env, _lib.ENV_LAYOUT_TILED_4X4))
         parts = r.gather(0)
         if rank == 0:
             np.save(out_path, torch.cat([p.cpu() for p in parts], 0).numpy())
@@ -198,7 +203,7 @@ def test_hip_strips_render_from_draw_calls(gpu, oracle, tmp_path):
     sd = [(d["positions"], d["triangles"], d["model"]) for d in draws]
     f.cube_shadow = oracle.point_shadow_maps(sd, f.lights, 32)
     f.dir_shadow = oracle.dir_shadow_map(sd, f.scene["light_space_matrix"], 64)
-    want = oracle.frame_chain(f)["ldr"]
+    want = oracle.frame_chain(f, oracle.skybox(_sky_cube(), f.scene, W, H))["ldr"]
     out_path = str(tmp_path / "ldr.npy")
     mp.spawn(_draws_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
     got = np.load(out_path)

@@ -543,3 +543,26 @@ def test_gbuffer_of_a_strip_is_the_strip_of_the_frame(oracle):
         part = oracle.gbuffer(draws, scene, w, rows, h, row0)
         for a, b in zip(part, whole):
             assert np.array_equal(a, b[row0:row0 + rows])
+
+
+def test_skybox_known_answers(oracle):
+    """A cube with one constant colour per face: a camera at the origin looking down -z with a 90 degree
+    square frustum sees exactly the -z face; rows of a strip equal the rows of the whole frame."""
+    n = 4
+    env = np.zeros((6, n, n, 4), dtype=np.float32)
+    for f in range(6):
+        env[f, ..., :3] = (f + 1, 10 * (f + 1), 0.5)
+    env[..., 3] = 1.0
+    env = np.ascontiguousarray(env.astype(np.float16)).view(np.uint16)
+    s = synth.default_scene_info().copy()
+    s["camera_view"] = np.eye(4, dtype=np.float32).ravel()
+    s["camera_projection"] = synth.perspective(90.0, 1.0, 0.1, 100.0).astype(np.float32).ravel()
+    sky = oracle.f16_to_f32(oracle.skybox(env, s, 16, 16))
+    inner = sky[2:-2, 2:-2]   # within half a texel of the face's edge the linear filter mixes in the neighbour face
+    assert (inner[..., 0] == 6.0).all() and (inner[..., 1] == 60.0).all() and (sky[..., 3] == 1.0).all()
+    # looking down +x: rotate the camera, the view matrix is the inverse rotation
+    s["camera_view"] = synth.look_at((0, 0, 0), (1, 0, 0), (0, 1, 0)).astype(np.float32).ravel()
+    sky_x = oracle.f16_to_f32(oracle.skybox(env, s, 16, 16))
+    assert (sky_x[2:-2, 2:-2, 0] == 1.0).all() and (sky_x[0, :, 0] != 1.0).all()
+    whole = oracle.skybox(env, s, 16, 16)
+    assert np.array_equal(oracle.skybox(env, s, 16, 5, frame_rows=16, row0=7), whole[7:12])

@@ -31,18 +31,21 @@ class OracleBackend:
 
     def shade(self, frame, color, thr):
         from tests import oracle
-        c, t = oracle.shade(frame, coverage=getattr(frame, "coverage_masks", None))
+        c, t = oracle.shade(frame, getattr(frame, "background_image", None), coverage=getattr(frame, "coverage_masks", None))
         self._bits(color)[...] = c
         self._bits(thr)[...] = t
 
-    def frame_from_draws(self, frame, draws, shadow_res, dir_res, frame_rows, row0):
+    def frame_from_draws(self, frame, draws, shadow_res, dir_res, frame_rows, row0, env=None):
         import dataclasses
         from tests import oracle
         a, n, m, p = oracle.gbuffer(draws, frame.scene, frame.width, frame.height, frame_rows, row0)
         sd = [(d["positions"], d["triangles"], d["model"]) for d in draws]
-        return dataclasses.replace(frame, albedo=a, normal=n, arm=m, position=p,
-                                   cube_shadow=oracle.point_shadow_maps(sd, frame.lights, shadow_res),
-                                   dir_shadow=oracle.dir_shadow_map(sd, frame.scene["light_space_matrix"], dir_res))
+        out = dataclasses.replace(frame, albedo=a, normal=n, arm=m, position=p,
+                                  cube_shadow=oracle.point_shadow_maps(sd, frame.lights, shadow_res),
+                                  dir_shadow=oracle.dir_shadow_map(sd, frame.scene["light_space_matrix"], dir_res))
+        if env is not None:
+            out.background_image = oracle.skybox(env[0], frame.scene, frame.width, frame.height, frame_rows, row0)
+        return out
 
     def with_coverage(self, frame, volume_mesh, frame_rows, row0):
         from tests import oracle
@@ -140,6 +143,10 @@ def _scene_draws():
                  albedo=alb, normal=nmap, arm=arm)]
 
 
+def _sky_cube():
+    return synth.make_env_cube(np.random.default_rng(12), 16)
+
+
 def _draws_frame():
     f = _frame()
     f.scene = f.scene.copy()
@@ -156,7 +163,7 @@ def _draws_worker(rank, world, port, out_path):
         f = _draws_frame()
         plan = StripPlan.make(rank, world, H)
         r = StripRenderer(plan, W, backend=OracleBackend())
-        r.render_draws(f.rows(plan.row0, plan.row0 + plan.rows), _scene_draws(), 16, 32)
+        r.render_draws(f.rows(plan.row0, plan.row0 + plan.rows), _scene_draws(), 16, 32, env=(_sky_cube(), 0))
         parts = r.gather(0)
         if rank == 0:
             np.save(out_path, torch.cat(parts, 0).numpy())
@@ -165,16 +172,16 @@ def _draws_worker(rank, world, port, out_path):
 
 
 def test_strips_render_a_frame_from_draw_calls(tmp_path, oracle):
-    """Every rank rasterises its own rows of the G-buffer (row0 of total_rows enters the projection) and all the
-    shadow maps; the assembled image is the single-device frame rendered from the same draw calls."""
+    """Every rank rasterises its own rows of the G-buffer and of the skybox (row0 of total_rows enters the
+    projection) and all the shadow maps; the assembled image is the single-device frame from the same draw calls."""
     f = _draws_frame()
     draws = _scene_draws()
     f.albedo, f.normal, f.arm, f.position = oracle.gbuffer(draws, f.scene, W, H)
     sd = [(d["positions"], d["triangles"], d["model"]) for d in draws]
     f.cube_shadow = oracle.point_shadow_maps(sd, f.lights, 16)
     f.dir_shadow = oracle.dir_shadow_map(sd, f.scene["light_space_matrix"], 32)
-    want = oracle.frame_chain(f)["ldr"]
-    assert (f.albedo[..., 3] != 0).mean() > 0.2
+    want = oracle.frame_chain(f, oracle.skybox(_sky_cube(), f.scene, W, H))["ldr"]
+    assert 0.2 < (f.albedo[..., 3] != 0).mean() < 0.98   # geometry and sky both in view
     out_path = str(tmp_path / "ldr.npy")
     mp.spawn(_draws_worker, args=(3, _free_port(), out_path), nprocs=3, join=True)
     assert np.array_equal(np.load(out_path), want)

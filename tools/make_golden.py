@@ -247,6 +247,43 @@ def gpass_vectors(spv_dir):
     print("gpass vectors written")
 
 
+def skybox_vectors(spv_dir):
+    """cubemap.vert and skybox.frag (the skybox draw of the composition pass) for points on the unit cube that
+    project onto chosen pixel centres: gl_Position of the vertex shader and the colour of the fragment shader."""
+    from vulkanrenderer_amd import synth
+    vs = Shader(os.path.join(spv_dir, "cubemap.vert.spv"))
+    fs = Shader(os.path.join(spv_dir, "skybox.frag.spv"))
+    rng = np.random.default_rng(47)
+    W, H = 48, 27
+    env_bits = synth.make_env_cube(np.random.default_rng(48), 8, sun_peak=6.0)
+    env = TexCube(h2f(env_bits), "linear")
+    cols = lambda m: [np.asarray(r, dtype=np.float32) for r in np.asarray(m, dtype=np.float32).reshape(4, 4)]
+    scenes, pixels, points, clip, colour = [], [], [], [], []
+    for cam, target in (((2.0, 1.6, -4.0), (0.0, 0.0, 0.0)), ((0.0, 0.0, 0.0), (1.0, 1.0, 1.0)), ((1.0, 5.0, 1.0), (1.0, 0.0, 1.001))):
+        scene = synth.default_scene_info().copy()
+        scene["camera_view"] = synth.look_at(cam, target, (0, 1, 0)).astype(np.float32).ravel()
+        scene["camera_projection"] = synth.perspective(60.0, W / H, 0.1, 100.0).astype(np.float32).ravel()
+        scene["camera_position"] = cam
+        V = np.asarray(scene["camera_view"], dtype=np.float64).reshape(4, 4)
+        P = np.asarray(scene["camera_projection"], dtype=np.float64).reshape(4, 4)
+        block = [cols(scene["camera_view"]), cols(scene["camera_projection"])]
+        px = np.stack([rng.integers(0, W, 16), rng.integers(0, H, 16)], -1)
+        px[:4] = [(0, 0), (W - 1, 0), (0, H - 1), (W - 1, H - 1)]
+        for x, y in px:
+            ndc = np.array([(2 * x + 1) / W - 1, (2 * y + 1) / H - 1])
+            ray_view = np.array([ndc[0] / P[0, 0], ndc[1] / P[1, 1], -1.0])
+            ray = V[:3, :3] @ ray_view                       # row-vector convention: world = view * R^T
+            q = (ray / np.abs(ray).max()).astype(np.float32)  # the point of the unit cube on that ray
+            points.append(q)
+            clip.append(vs.run({0: q}, {(0, 0): block})["out"]["builtin"][0])
+            colour.append(fs.run({0: q}, {(1, 0): env})["out"][0])
+        scenes.append(scene); pixels.append(px)
+    np.savez_compressed(os.path.join(OUT, "skybox.npz"), width=W, height=H, env=env_bits, scenes=np.stack(scenes),
+                        pixels=np.stack(pixels), points=np.array(points).reshape(3, 16, 3),
+                        gl_position=np.array(clip).reshape(3, 16, 4), colour=np.array(colour).reshape(3, 16, 4))
+    print("skybox vectors written")
+
+
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     spv = args[0] if args else "/root/reference/compiled_shaders"
@@ -254,7 +291,10 @@ if __name__ == "__main__":
         light_vert_vectors(spv)
     elif "--only-gpass" in sys.argv:
         gpass_vectors(spv)
+    elif "--only-skybox" in sys.argv:
+        skybox_vectors(spv)
     else:
         main(spv)
         light_vert_vectors(spv)
         gpass_vectors(spv)
+        skybox_vectors(spv)

@@ -137,6 +137,7 @@ PROTOTYPES = {
     "vkr_light_coverage": [C.POINTER(CoverageArgs), _vp],
     "vkr_point_shadow_maps": [C.POINTER(PointShadowArgs), _vp],
     "vkr_gbuffer": [C.POINTER(GpassArgs), _vp],
+    "vkr_skybox": [_vp, _i32, _i32, C.POINTER(SceneInfo), _i32, _i32, _i32, _i32, _vp, _vp],
     "vkr_gbuffer_workspace_bytes": [_i32, _i32, _i32],
     "vkr_dir_shadow_map": [C.POINTER(DirShadowArgs), _vp],
     "vkr_bloom_blur": [C.POINTER(BloomArgs), _vp],

@@ -128,6 +128,7 @@ static void destroy(vkr_ctx *c)
 static int32_t run_coverage(vkr_ctx *c, Frame &f);
 static int32_t run_shadow_passes(vkr_ctx *c, Frame &f);
 static int32_t run_geometry_pass(vkr_ctx *c, Frame &f);
+static int32_t run_skybox(vkr_ctx *c, Frame &f);
 
 #define VKR_CTX(c)                                                   \
     VKR_REQUIRE((c) != nullptr, "%s: context is null", __func__);    \
@@ -140,7 +141,7 @@ static int32_t fill_shade_args(vkr_ctx *c, Frame &f, VkrShadeArgs &a)
     memset(&a, 0, sizeof(a));
     a.width = c->cfg.width; a.rows = c->cfg.height;
     a.albedo = f.gbuf[0]; a.normal = f.gbuf[1]; a.arm = f.gbuf[2]; a.position = f.gbuf[3];
-    a.background = f.has_background ? f.background : nullptr;
+    a.background = f.has_background || c->have_env ? f.background : nullptr;  // uploaded, or drawn by run_skybox
     a.scene = f.scene;
     a.lights = f.lights; a.n_lights = f.n_lights; a.coverage_mode = f.coverage;
     a.dir_shadow = f.dir_shadow; a.dir_res = c->cfg.dir_shadow_res;
@@ -223,6 +224,16 @@ static int32_t run_coverage(vkr_ctx *c, Frame &f)
     a.indices = c->mesh_indices; a.n_tris = c->mesh_n_tris;
     a.masks = f.coverage_buf;
     return vkr_light_coverage(&a, c->stream);
+}
+
+// The skybox draw that opens the composition pass (VulkanRenderer.cs:436-443), from the environment cube.
+// An image given with vkr_upload_background for this frame takes its place.
+static int32_t run_skybox(vkr_ctx *c, Frame &f)
+{
+    if (f.has_background || !c->have_env) return VKR_OK;
+    const void *env = c->env_tiled ? c->env_tiled : c->env;
+    const int32_t layout = c->env_tiled ? VKR_ENV_LAYOUT_TILED_4X4 : VKR_ENV_LAYOUT_LINEAR;
+    return vkr_skybox(env, c->cfg.env_res, layout, &f.scene, c->cfg.width, c->cfg.height, c->cfg.height, 0, f.background, c->stream);
 }
 
 static VkrBloomArgs bloom_args(vkr_ctx *c, Frame &f, int horizontal)
@@ -610,6 +621,7 @@ extern "C" int32_t vkr_pass_composition(vkr_ctx *c)
     if ((rc = run_shadow_passes(c, c->frames[c->frame])) != VKR_OK) return rc;
     if ((rc = run_geometry_pass(c, c->frames[c->frame])) != VKR_OK) return rc;
     if ((rc = run_coverage(c, c->frames[c->frame])) != VKR_OK) return rc;
+    if ((rc = run_skybox(c, c->frames[c->frame])) != VKR_OK) return rc;
     return vkr_shade(&a, c->stream);
 }
 
@@ -642,7 +654,8 @@ extern "C" int32_t vkr_end_frame(vkr_ctx *c)
     VKR_HIP_CHECK(hipEventRecord(c->ev[0], c->stream));
     if ((rc = run_shadow_passes(c, f)) != VKR_OK) return rc;   // EndFrame's order: point shadows, geometry, directional shadow
     if ((rc = run_geometry_pass(c, f)) != VKR_OK) return rc;
-    if ((rc = run_coverage(c, f)) != VKR_OK) return rc;  // both counted with the composition pass in the timing
+    if ((rc = run_coverage(c, f)) != VKR_OK) return rc;  // counted with the composition pass in the timing, like the skybox
+    if ((rc = run_skybox(c, f)) != VKR_OK) return rc;
     if ((rc = vkr_shade(&a, c->stream)) != VKR_OK) return rc;
     VKR_HIP_CHECK(hipEventRecord(c->ev[1], c->stream));
     VkrBloomArgs b1 = bloom_args(c, f, 1);

@@ -194,6 +194,30 @@ __global__ __launch_bounds__(256) void gpass_resolve_kernel(const GpassParams p)
     p.position[px] = pack4(pos[0], pos[1], pos[2], pos[3]);
 }
 
+// Skybox draw of the composition pass (VulkanRenderer.cs:436-443; cubemap.vert, skybox.frag): the cube lookup
+// depends only on the direction of the interpolated cube position, i.e. on the pixel's view ray
+// (xn / proj[0][0], yn / proj[1][1], -1) turned into world space by the transposed view rotation.
+struct SkyboxParams {
+    const void *env; int env_n; int tiled;
+    float view[16]; float ipx, ipy;
+    int width, rows, frame_rows, row0;
+    uint2 *out;
+};
+
+template <bool TILED>
+__global__ __launch_bounds__(256) void skybox_kernel(const SkyboxParams p)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= p.width || y >= p.rows) return;
+    const float sx = 2.0f / (float)p.width, sy = 2.0f / (float)p.frame_rows;
+    const float xn = fma_((float)x + 0.5f, sx, -1.0f), yn = fma_((float)(p.row0 + y) + 0.5f, sy, -1.0f);
+    const float vx = xn * p.ipx, vy = yn * p.ipy, vz = -1.0f;
+    const float *V = p.view;
+    const f3 d = mk3(fma_(vz, V[2], fma_(vy, V[1], vx * V[0])), fma_(vz, V[6], fma_(vy, V[5], vx * V[4])), fma_(vz, V[10], fma_(vy, V[9], vx * V[8])));
+    const f3 c = texcube_rgb_linear<TILED>(p.env, p.env_n, d);
+    p.out[(size_t)y * p.width + x] = pack4(c.x, c.y, c.z, 1.0f);
+}
+
 __global__ __launch_bounds__(256) void fill_u64_kernel(unsigned long long *out, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -256,4 +280,24 @@ extern "C" int32_t vkr_gbuffer(const VkrGpassArgs *a, void *stream)
     }
     hipLaunchKernelGGL(gpass_resolve_kernel, dim3((unsigned)((a->width + 63) / 64), (unsigned)((a->rows + 3) / 4)), dim3(256), 0, as_stream(stream), p);
     return launch_status("vkr_gbuffer");
+}
+
+extern "C" int32_t vkr_skybox(const void *env, int32_t env_n, int32_t env_layout, const VkrSceneInfo *scene,
+                              int32_t width, int32_t rows, int32_t frame_rows, int32_t row0, void *out_rgba16f, void *stream)
+{
+    using namespace vkr;
+    VKR_REQUIRE(env && scene && out_rgba16f && env_n > 0, "vkr_skybox: an image or the scene is null");
+    VKR_REQUIRE(width > 0 && rows > 0 && frame_rows >= rows && row0 >= 0 && row0 + rows <= frame_rows, "vkr_skybox: bad size %dx%d, rows [%d,%d) of %d", width, rows, row0, row0 + rows, frame_rows);
+    VKR_REQUIRE(env_layout == VKR_ENV_LAYOUT_LINEAR || (env_layout == VKR_ENV_LAYOUT_TILED_4X4 && env_n % 4 == 0), "vkr_skybox: layout %d not usable with face size %d", env_layout, env_n);
+    VKR_REQUIRE(scene->camera_projection[0] != 0.0f && scene->camera_projection[5] != 0.0f, "vkr_skybox: the projection matrix has a zero scale");
+    SkyboxParams p;
+    p.env = env; p.env_n = env_n; p.tiled = env_layout == VKR_ENV_LAYOUT_TILED_4X4;
+    for (int i = 0; i < 16; i++) p.view[i] = scene->camera_view[i];
+    p.ipx = 1.0f / scene->camera_projection[0]; p.ipy = 1.0f / scene->camera_projection[5];
+    p.width = width; p.rows = rows; p.frame_rows = frame_rows; p.row0 = row0;
+    p.out = (uint2 *)out_rgba16f;
+    const dim3 grid((unsigned)((width + 63) / 64), (unsigned)((rows + 3) / 4));
+    if (p.tiled) hipLaunchKernelGGL(skybox_kernel<true>, grid, dim3(256), 0, as_stream(stream), p);
+    else hipLaunchKernelGGL(skybox_kernel<false>, grid, dim3(256), 0, as_stream(stream), p);
+    return launch_status("vkr_skybox");
 }

@@ -176,6 +176,17 @@ def gbuffer(draws, scene: np.ndarray, width: int, rows: int, device, frame_rows:
     return tuple(out)
 
 
+def skybox(env: torch.Tensor, scene: np.ndarray, width: int, rows: int, frame_rows: int | None = None, row0: int = 0,
+           env_layout: int = _lib.ENV_LAYOUT_LINEAR) -> torch.Tensor:
+    """The skybox draw of the composition pass: float16 [rows, width, 4], the `background` of a DeviceFrame."""
+    lib = _lib.load()
+    out = torch.empty((rows, width, 4), dtype=torch.float16, device=env.device)
+    sc = _scene_struct(scene)
+    _lib.check(lib.vkr_skybox(_ptr(env), env.shape[1], env_layout, C.byref(sc), width, rows,
+                              rows if frame_rows is None else frame_rows, row0, _ptr(out), _stream()))
+    return out
+
+
 def tile_depth_cubes(linear: torch.Tensor) -> torch.Tensor:
     """[..., res, res] float32 depth faces, row-major -> the same faces as 8x4-texel tiles (new tensor)."""
     lib = _lib.load()

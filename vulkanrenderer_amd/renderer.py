@@ -10,8 +10,11 @@ call to the renderer object of libvkr_hip.so (layer 2 of include/vkr_hip.h):
     CreateSkyboxCubemap(...) etc.  VulkanRenderer.cs:653,734,815,966   synchronous IBL precompute
     WaitIdle()                     blocks until the device is idle
 
-The geometry, shadow-map and skybox draws of the reference are outside this path; their results
-enter through UploadGBuffer / UploadDirectionalShadowMap / UploadPointShadowMap / UploadBackground.
+    CreateMesh / CreateMaterial / DrawModel(...)   Mesh.cs, Material.cs, VulkanRenderer.cs:630
+
+EndFrame renders the shadow maps and the G-buffer from the frame's draw calls and the skybox from the
+environment cube; a caller that renders those itself hands the images over with UploadGBuffer /
+UploadDirectionalShadowMap / UploadPointShadowMap / UploadBackground.
 """
 from __future__ import annotations
 

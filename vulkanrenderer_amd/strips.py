@@ -66,12 +66,15 @@ class HipBackend:
     def shade(self, frame, color, thr):
         self.P.shade(frame, color, thr)
 
-    def frame_from_draws(self, frame, draws, shadow_res, dir_res, frame_rows, row0):
+    def frame_from_draws(self, frame, draws, shadow_res, dir_res, frame_rows, row0, env=None):
         """This strip's G-buffer and the (replicated) shadow maps rendered from draw calls: `frame` supplies the
         scene constants, lights and IBL images; `draws` are the dicts passes.gbuffer takes.  Each rank renders
-        all shadow maps itself: re-rendering 64 cubes (2.3 ms) is cheaper than moving 1.5 GB between GPUs."""
+        all shadow maps itself: re-rendering 64 cubes (2.3 ms) is cheaper than moving 1.5 GB between GPUs.
+        `env` = (environment cube tensor, VKR_ENV_LAYOUT_*): the skybox is drawn behind the strip's geometry."""
         import dataclasses
         P = self.P
+        if env is not None:
+            frame = dataclasses.replace(frame, background=P.skybox(env[0], frame.scene, frame.width, frame.rows, frame_rows, row0, env_layout=env[1]))
         ga, gn, gm, gp = P.gbuffer(draws, frame.scene, frame.width, frame.rows, self.device, frame_rows, row0)
         sd = [(d["positions"], d["triangles"], d["model"]) for d in draws]
         cubes, layout = P.point_shadow_maps(sd, frame.lights, frame.n_lights, shadow_res)
@@ -132,11 +135,14 @@ class StripRenderer:
         for req in self.start_halo_exchange():
             req.wait()
 
-    def render_draws(self, frame, draws, shadow_res: int, dir_res: int, volume_mesh=None) -> torch.Tensor:
+    def render_draws(self, frame, draws, shadow_res: int, dir_res: int, volume_mesh=None, env=None) -> torch.Tensor:
         """A frame from draw calls: this strip's part of the geometry pass (placed in the frame by plan.row0),
-        the shadow passes, then render().  `frame` carries scene constants, lights and IBL images."""
+        the shadow passes, the skybox when an environment cube is given, then render().  `frame` carries scene
+        constants, lights and IBL images."""
         p = self.plan
-        return self.render(self.backend.frame_from_draws(frame, draws, shadow_res, dir_res, p.total_rows, p.row0), volume_mesh)
+        if env is None:
+            return self.render(self.backend.frame_from_draws(frame, draws, shadow_res, dir_res, p.total_rows, p.row0), volume_mesh)
+        return self.render(self.backend.frame_from_draws(frame, draws, shadow_res, dir_res, p.total_rows, p.row0, env), volume_mesh)
 
     def render(self, frame, volume_mesh=None) -> torch.Tensor:
         """composition -> bloom 1 -> halo exchange overlapped with the interior rows of bloom 2 +
