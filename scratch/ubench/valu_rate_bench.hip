@@ -1,0 +1,105 @@
+// Microbenchmark 3: issue rate of single and packed FP32 VALU instructions on gfx950, and of the
+// integer / conversion instructions the shadow-tap address arithmetic uses.  Every kernel runs the
+// same number of instructions per lane in 8 independent dependency chains.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+constexpr int ITER = 4096;
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+template <int MODE>
+__global__ __launch_bounds__(256) void rate_kernel(float *out, float a, float b)
+{
+    float x[8];
+    float2_t p[8];
+    int n[8];
+    unsigned long long m[8] = {};
+#pragma unroll
+    for (int k = 0; k < 8; k++) { x[k] = (float)(threadIdx.x + k); p[k] = float2_t{x[k], x[k] + 1.0f}; n[k] = threadIdx.x + k; }
+    const float2_t pa = {a, a}, pb = {b, b};
+    for (int it = 0; it < ITER; it++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (MODE == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[k]) : "v"(a), "v"(b));
+            if (MODE == 1) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[k]) : "v"(pa), "v"(pb));
+            if (MODE == 2) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[k]) : "v"(a));
+            if (MODE == 3) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[k]) : "v"(pa));
+            if (MODE == 4) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[k]) : "v"(pa));
+            if (MODE == 5) asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(n[k]) : "v"(n[0]));
+            if (MODE == 6) asm volatile("v_cvt_flr_i32_f32 %0, %1" : "=v"(n[k]) : "v"(x[k]));
+            if (MODE == 7) asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(n[k]) : "v"(x[k]));
+            if (MODE == 8) asm volatile("v_add_lshl_u32 %0, %0, %1, 2" : "+v"(n[k]) : "v"(n[0]));
+            if (MODE == 9) asm volatile("v_cmp_gt_f32 vcc, %0, %1\n\tv_addc_co_u32 %2, vcc, 0, %2, vcc" : : "v"(x[k]), "v"(a), "v"(n[k]) : "vcc");
+            if (MODE == 10) asm volatile("v_med3_i32 %0, %0, 0, %1" : "+v"(n[k]) : "v"(n[0]));
+            if (MODE == 12) asm volatile("v_rcp_f32 %0, %0" : "+v"(x[k]));
+            if (MODE == 13) asm volatile("v_rsq_f32 %0, %0" : "+v"(x[k]));
+            if (MODE == 14) asm volatile("v_sqrt_f32 %0, %0" : "+v"(x[k]));
+            if (MODE == 15) asm volatile("v_max_f32 %0, %0, %1" : "+v"(x[k]) : "v"(a));
+            if (MODE == 16) asm volatile("v_floor_f32 %0, %0" : "+v"(x[k]));
+            if (MODE == 17) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[k]) : "v"(a) : "vcc");
+            if (MODE == 18) asm volatile("v_fma_mix_f32 %0, %0, %1, %2 op_sel_hi:[0,0,1]" : "+v"(x[k]) : "v"(a), "v"(n[k]));
+            if (MODE == 19) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(n[k]) : "v"(x[k]), "v"(a));
+            if (MODE == 20) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[k]) : "v"(a));
+            if (MODE == 21) asm volatile("v_max3_f32 %0, |%0|, |%1|, |%2|" : "+v"(x[k]) : "v"(a), "v"(b));
+            if (MODE == 22) asm volatile("v_cmp_gt_f32 %0, %1, %2" : "=s"(m[k]) : "v"(x[k]), "v"(a));
+            if (MODE == 23) asm volatile("v_lshl_add_u32 %0, %0, 5, %1" : "+v"(n[k]) : "v"(n[0]));
+            if (MODE == 11) asm volatile("v_cvt_f16_f32 %0, %0\n\tv_cvt_f32_f16 %0, %0" : "+v"(x[k]));
+        }
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) s += x[k] + p[k].x + p[k].y + (float)n[k] + (float)m[k];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int MODE>
+static void run(const char *name, float *out, double per_instr_lane_ops, int instr_per_iter = 8)
+{
+    const int blocks = 256 * 16;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(rate_kernel<MODE>, dim3(blocks), dim3(256), 0, 0, out, 1.0001f, 0.5f);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(rate_kernel<MODE>, dim3(blocks), dim3(256), 0, 0, out, 1.0001f, 0.5f);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipDeviceSynchronize());
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double wave_instr = (double)blocks * 4 * ITER * instr_per_iter;   // wave-level instructions
+    const double per_simd_clk = wave_instr / 1024.0 / (ms * 1e-3) / 2.4e9;  // instructions per SIMD per 2.4 GHz clock
+    printf("%-28s %8.3f ms  %6.3f wave-instr/SIMD/clk@2.4GHz  (%5.2f clk each)  %7.1f Gop/s lane ops\n", name, ms, per_simd_clk, 1.0 / per_simd_clk,
+           wave_instr * 64 * per_instr_lane_ops / (ms * 1e-3) / 1e9);
+}
+
+int main()
+{
+    float *out;
+    CHECK(hipMalloc(&out, 256 * 16 * 256 * 4));
+    run<0>("v_fma_f32", out, 2);
+    run<1>("v_pk_fma_f32", out, 4);
+    run<2>("v_mul_f32", out, 1);
+    run<3>("v_pk_mul_f32", out, 2);
+    run<4>("v_pk_add_f32", out, 2);
+    run<5>("v_mad_u32_u24", out, 1);
+    run<6>("v_cvt_flr_i32_f32", out, 1);
+    run<7>("v_alignbit_b32", out, 1);
+    run<8>("v_add_lshl_u32", out, 1);
+    run<9>("v_cmp_gt_f32 + v_addc", out, 1, 16);
+    run<10>("v_med3_i32", out, 1);
+    run<11>("cvt_f16_f32 + cvt_f32_f16", out, 1, 16);
+    run<12>("v_rcp_f32", out, 1);
+    run<13>("v_rsq_f32", out, 1);
+    run<14>("v_sqrt_f32", out, 1);
+    run<15>("v_max_f32", out, 1);
+    run<16>("v_floor_f32", out, 1);
+    run<17>("v_cndmask_b32", out, 1);
+    run<18>("v_fma_mix_f32", out, 2);
+    run<19>("v_cvt_pk_f16_f32", out, 2);
+    run<20>("v_add_f32", out, 1);
+    run<21>("v_max3_f32 |.|", out, 1);
+    run<22>("v_cmp_gt_f32 -> sgpr", out, 1);
+    run<23>("v_lshl_add_u32", out, 1);
+    return 0;
+}

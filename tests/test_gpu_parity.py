@@ -876,3 +876,15 @@ def test_skybox_bit_exact(gpu, oracle, w, h, row0, frame_rows):
     bad["camera_projection"] = np.zeros(16, dtype=np.float32)
     with pytest.raises(_lib.VkrError):
         P.skybox(dev_env, bad, w, h, frame_rows, row0)
+
+
+def test_fast_reciprocal_and_square_root_are_correctly_rounded(gpu):
+    """vkr_selftest_math sweeps all 2^32 binary32 patterns on the device: the fast reciprocal (one Newton
+    step), the fast square root and the pair the shading kernel uses return IEEE's bits on their domains."""
+    import ctypes
+    counts = (ctypes.c_uint64 * 7)()
+    _lib.check(_lib.load().vkr_selftest_math(counts))
+    rcp1, _, sqrt_, rcp_of_sqrt, pair, n_rcp, n_sqrt = list(counts)
+    assert n_rcp > 4.2e9 and n_sqrt > 2.1e9
+    assert (rcp1, sqrt_, rcp_of_sqrt) == (0, 0, 0)
+    assert pair == 0

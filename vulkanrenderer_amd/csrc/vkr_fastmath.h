@@ -1,8 +1,9 @@
 // Correctly rounded reciprocal and square root built from the hardware's 1-ulp estimates
-// (v_rcp_f32, v_sqrt_f32) and fused multiply-adds.  They return the same bits as IEEE 1/x and
+// (v_rcp_f32, v_rsq_f32) and fused multiply-adds.  They return the same bits as IEEE 1/x and
 // sqrt(x) on these domains: fast_rcp_rn for 2^-126 <= |x| < 2^126 (x and 1/x both normal),
-// fast_sqrt_rn for 2^-96 <= x; vkr_selftest_math() checks both exhaustively on the device.
-// They cost 3 and 9 instructions instead of the ~11 and ~14 of the compiler's IEEE expansions.
+// fast_sqrt_rn for 2^-96 <= x <= 2^96; vkr_selftest_math() checks both exhaustively on the device.
+// They cost 3 and 5 instructions instead of the ~11 and ~14 of the compiler's IEEE expansions, and
+// apart from the estimate only multiplies and fmas, which issue faster than compares and selects.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -37,18 +38,15 @@ VKR_FM_DEV float rcp_rn_checked(float x)
     return fast_rcp_rn(x);
 }
 
-// RN(sqrt(x)): hardware estimate s (within 1 ulp), then pick among s and its two neighbours by
-// the sign of the exact residuals x - s*down and x - s*up (each one fma).
+// RN(sqrt(x)): y = hardware estimate of 1/sqrt(x), g = x*y a root within an ulp or so, then one
+// correction with the exact residual x - g*g (Markstein's final step).  No input in the domain
+// rounds the wrong way (swept exhaustively).
 VKR_FM_DEV float fast_sqrt_rn(float x)
 {
-    float s = __builtin_amdgcn_sqrtf(x);
-    unsigned int sb = __builtin_bit_cast(unsigned int, s);
-    float down = __builtin_bit_cast(float, sb - 1u), up = __builtin_bit_cast(float, sb + 1u);
-    float rd = __builtin_fmaf(-down, s, x);
-    float ru = __builtin_fmaf(-up, s, x);
-    s = rd <= 0.0f ? down : s;
-    s = ru > 0.0f ? up : s;
-    return s;
+    float y = __builtin_amdgcn_rsqf(x);
+    float g = x * y, h = 0.5f * y;
+    float r = __builtin_fmaf(-g, g, x);
+    return __builtin_fmaf(r, h, g);
 }
 
 // RN(sqrt(x)) for every x: zero returns itself, everything else outside [2^-96, 2^96] takes the

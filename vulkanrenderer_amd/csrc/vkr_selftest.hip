@@ -5,7 +5,7 @@
 
 namespace vkr {
 
-// counts[0] rcp (1 Newton step)   counts[1] rcp (2 steps)   counts[2] sqrt on x >= 2^-96
+// counts[0] rcp (1 Newton step)   counts[1] rcp (2 steps)   counts[2] sqrt on 2^-96 <= x <= 2^96
 // counts[3] rcp applied to IEEE sqrt(x)   counts[4] the sqrt + reciprocal pair as shipped
 // counts[5] patterns tested for rcp   counts[6] patterns tested for sqrt
 __global__ __launch_bounds__(256) void selftest_math_kernel(unsigned long long *counts)
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void selftest_math_kernel(unsigned long long *
         local[6]++;
         float sw = __builtin_sqrtf(x), iw = 1.0f / sw;
         float s = fast_sqrt_rn(x);
-        if (ex >= 31 && __builtin_bit_cast(unsigned int, s) != __builtin_bit_cast(unsigned int, sw)) local[2]++;  // x >= 2^-96
+        if (x >= 0x1p-96f && x <= 0x1p96f && __builtin_bit_cast(unsigned int, s) != __builtin_bit_cast(unsigned int, sw)) local[2]++;
         if (__builtin_bit_cast(unsigned int, fast_rcp_rn(sw)) != __builtin_bit_cast(unsigned int, iw)) local[3]++;
         float s2, inv2;
         sqrt_and_rcp_rn(x, s2, inv2);

@@ -150,12 +150,34 @@ VKR_DEV int face_texel(float c, float ima, float fres, int res)
     return r;
 }
 
+// face_texel for a coordinate known to satisfy |c| <= |major| * (1 - 2^-21): the scaled value then lies
+// in (0, res) after rounding, so the clamp of the general rule never acts and is left out.
+template <bool POW2>
+VKR_DEV int face_texel_inside(float c, float ima, float fres)
+{
+    const float q = c * ima;
+    const float scaled = POW2 ? fma_(q, 0.5f * fres, 0.5f * fres) : fma_(q, 0.5f, 0.5f) * fres;
+    int i;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(i) : "v"(scaled));
+    return i;
+}
+
+// 1.0 where cur > closest, else 0.0, as one FP32 instruction: cur_s = cur * 2^60 (exact).  cur is a
+// distance minus 0.15, so a positive cur is at least 2^-27 and a non-zero cur - closest at least 2^-51 in
+// magnitude: times 2^60 it saturates the [0, 1] clamp of the instruction; zero, negative and NaN give 0.
+VKR_DEV float step_closer(float closest, float cur_s)
+{
+    float t;
+    asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(t) : "v"(closest), "s"(-0x1p60f), "v"(cur_s));
+    return t;
+}
+
 // Number of the 20 taps whose stored depth is closer than `cur` when every tap of every lane of
 // the wave lies on cube face `face` (wave-uniform).  U, W are the coordinates that become sc, tc
 // (sign already applied), IM the reciprocals of |major coordinate|; the index triple of a tap is
 // permuted so that (iu, iw, im) index U, W, IM.
 template <int AXIS, bool TILED, bool POW2>
-VKR_DEV int taps_one_face(const float *face_base, int res, const float (&X)[3], const float (&Y)[3], const float (&Z)[3], bool neg, float cur)
+VKR_DEV float taps_one_face(const float *face_base, int res, const float (&X)[3], const float (&Y)[3], const float (&Z)[3], bool neg, float cur)
 {
     const float fres = (float)res;
     const float (&M)[3] = AXIS == 2 ? Z : (AXIS == 1 ? Y : X);
@@ -163,7 +185,10 @@ VKR_DEV int taps_one_face(const float *face_base, int res, const float (&X)[3], 
 #pragma unroll
     for (int k = 0; k < 3; k++) IM[k] = fast_rcp_rn(__builtin_fabsf(M[k]));
     // z major: sc = +-x, tc = -y;  y major: sc = x, tc = +-z;  x major: sc = -+z, tc = -y
-    unsigned I[3][3], J[3][3];  // byte offsets of the column / row, [index into U / W][index into M]
+    // column offset in bytes, row offset in units of 32 bytes (tiled: (j>>2) * (res/8 tiles * 4) + j) or of
+    // one row (row-major); [index into U / W][index into M]
+    unsigned I[3][3], J[3][3];
+    const unsigned row_unit = TILED ? 32u : (unsigned)res * 4u;
 #pragma unroll
     for (int a = 0; a < 3; a++)
 #pragma unroll
@@ -173,24 +198,28 @@ VKR_DEV int taps_one_face(const float *face_base, int res, const float (&X)[3], 
             if (AXIS == 2) { u = neg ? -X[a] : X[a]; w = -Y[a]; }
             else if (AXIS == 1) { u = X[a]; w = neg ? -Z[a] : Z[a]; }
             else { u = neg ? Z[a] : -Z[a]; w = -Y[a]; }
-            I[a][m] = col_bytes<TILED>(face_texel<POW2>(u, IM[m], fres, res));
-            J[a][m] = row_bytes<TILED>(face_texel<POW2>(w, IM[m], fres, res), (unsigned)res);
+            I[a][m] = col_bytes<TILED>(face_texel_inside<POW2>(u, IM[m], fres));
+            const unsigned j = (unsigned)face_texel_inside<POW2>(w, IM[m], fres);
+            J[a][m] = TILED ? __umul24(j >> 2, ((unsigned)res >> 1) - 4u) + j : j;
         }
-    int count = 0;
+    const float cur_s = cur * 0x1p60f;
+    float count = 0.0f;
     const char *base = (const char *)face_base;
 #define VKR_TAP(gx, gy, gz)                                                              \
     {                                                                                    \
         constexpr int iu = AXIS == 0 ? gz : gx, iw = AXIS == 1 ? gz : gy, im = AXIS == 2 ? gz : (AXIS == 1 ? gy : gx); \
-        unsigned off = J[iw][im] + I[iu][im];                                            \
-        float closest = *(const float *)(base + off) * 25.0f;                            \
-        count += cur > closest ? 1 : 0;                                                  \
+        unsigned off;                                                                    \
+        if (TILED) asm("v_lshl_add_u32 %0, %1, 5, %2" : "=v"(off) : "v"(J[iw][im]), "v"(I[iu][im])); \
+        else off = __umul24(J[iw][im], row_unit) + I[iu][im];                            \
+        const float closest = *(const float *)(base + off) * 25.0f;                      \
+        count += step_closer(closest, cur_s);                                            \
     }
     VKR_GRID20A(VKR_TAP)
-    const int count_a = count;  // two independent chains of ten adds instead of one of twenty
-    count = 0;
+    const float count_a = count;  // two independent chains of ten adds instead of one of twenty
+    count = 0.0f;
     VKR_GRID20B(VKR_TAP)
 #undef VKR_TAP
-    return count + count_a;
+    return count + count_a;  // an integer in [0, 20], exact in binary32
 }
 
 // The same count with the cube face chosen per tap and per lane (light.frag:133 through
@@ -241,15 +270,22 @@ VKR_DEV int taps_any_face(const float *cube, int res, const float (&X)[3], const
 // the extreme candidates, so "agree" here implies the per-tap rule picks that face for each tap.
 VKR_DEV int common_face(const float (&X)[3], const float (&Y)[3], const float (&Z)[3])
 {
+    // X[0] <= X[1] <= X[2], so the largest magnitude is at an end; the third operand of the maximum keeps a
+    // winning major coordinate at 2^-100 or more, inside the domain of fast_rcp_rn
+    constexpr float TINY = 0x1p-100f;
     const float xmin = __builtin_fminf(__builtin_fabsf(X[0]), __builtin_fminf(__builtin_fabsf(X[1]), __builtin_fabsf(X[2])));
-    const float xmax = __builtin_fmaxf(__builtin_fabsf(X[0]), __builtin_fmaxf(__builtin_fabsf(X[1]), __builtin_fabsf(X[2])));
+    const float xmax = __builtin_fmaxf(__builtin_fabsf(X[0]), __builtin_fmaxf(TINY, __builtin_fabsf(X[2])));
     const float ymin = __builtin_fminf(__builtin_fabsf(Y[0]), __builtin_fminf(__builtin_fabsf(Y[1]), __builtin_fabsf(Y[2])));
-    const float ymax = __builtin_fmaxf(__builtin_fabsf(Y[0]), __builtin_fmaxf(__builtin_fabsf(Y[1]), __builtin_fabsf(Y[2])));
+    const float ymax = __builtin_fmaxf(__builtin_fabsf(Y[0]), __builtin_fmaxf(TINY, __builtin_fabsf(Y[2])));
     const float zmin = __builtin_fminf(__builtin_fabsf(Z[0]), __builtin_fminf(__builtin_fabsf(Z[1]), __builtin_fabsf(Z[2])));
-    const float zmax = __builtin_fmaxf(__builtin_fabsf(Z[0]), __builtin_fmaxf(__builtin_fabsf(Z[1]), __builtin_fabsf(Z[2])));
-    const bool zm = (zmin >= xmax) & (zmin >= ymax);   // z major for every combination
-    const bool ym = (zmax < ymin) & (ymin >= xmax);    // never z major, always y over x
-    const bool xm = (zmax < xmin) & (ymax < xmin);     // never z major, never y over x
+    const float zmax = __builtin_fmaxf(__builtin_fabsf(Z[0]), __builtin_fmaxf(TINY, __builtin_fabsf(Z[2])));
+    // The major coordinate must win by a margin (factor 1 - 2^-20): the one-face path then needs no clamp
+    // of its texel coordinates (face_texel_inside); combinations nearer a tie take the per-tap path.
+    constexpr float K = 1.0f - 0x1p-20f;
+    const float xs = xmin * K, ys = ymin * K, zs = zmin * K;
+    const bool zm = (zs >= xmax) & (zs >= ymax);       // z major for every combination
+    const bool ym = (zmax < ys) & (ys >= xmax);        // never z major, always y over x
+    const bool xm = (zmax < xs) & (ymax < xs);         // never z major, never y over x
     // the major coordinate keeps one sign over its three candidates exactly when the smallest
     // magnitude is not produced by a sign change, i.e. when v-r and v+r have the same sign
     const float lo = zm ? Z[0] : (ym ? Y[0] : X[0]), hi = zm ? Z[2] : (ym ? Y[2] : X[2]);
@@ -395,23 +431,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
                 if (m == 0) continue;
                 covered = (m >> lane) & 1ull;
             }
-            const f3 Lv = sub3(lp, pos);
-            float dist, inv_dist;
-            sqrt_and_rcp_rn(dot3(Lv, Lv), dist, inv_dist);
-            const f3 L = scale3(Lv, inv_dist);
+            // fragToLight = pos - lp; L is its negation normalised (a - b = -(b - a) bit for bit, and the
+            // squares in the length are the same)
+            const f3 Fv = sub3(pos, lp);
+            const float dist2 = dot3(Fv, Fv);
+            float dist, inv_dist, att;
+            if (__builtin_expect(!(dist2 >= 0x1p-96f && dist2 <= 0x1p96f), 0)) {
+                dist = __builtin_sqrtf(dist2);
+                inv_dist = 1.0f / dist;
+                att = 1.0f / (dist * dist);
+            } else {  // dist is within [2^-48, 2^48], its square well inside fast_rcp_rn's domain
+                dist = fast_sqrt_rn(dist2);
+                inv_dist = fast_rcp_rn(dist);
+                att = fast_rcp_rn(dist * dist);
+            }
+            const f3 L = mk3(-Fv.x * inv_dist, -Fv.y * inv_dist, -Fv.z * inv_dist);
             const float NdotL = max0(dot3(N, L));
-            // light.frag:121-141; |pos - lp| equals |lp - pos| bit for bit
+            // light.frag:121-141
             const float cur = dist - 0.15f;
-            const float X[3] = {pos.x - lp.x - disk, pos.x - lp.x, pos.x - lp.x + disk};
-            const float Y[3] = {pos.y - lp.y - disk, pos.y - lp.y, pos.y - lp.y + disk};
-            const float Z[3] = {pos.z - lp.z - disk, pos.z - lp.z, pos.z - lp.z + disk};
+            const float X[3] = {Fv.x - disk, Fv.x, Fv.x + disk};
+            const float Y[3] = {Fv.y - disk, Fv.y, Fv.y + disk};
+            const float Z[3] = {Fv.z - disk, Fv.z, Fv.z + disk};
             const float *cube = p.cube_shadow + (size_t)li * 6 * face_stride;
             const int face = common_face(X, Y, Z);
             const int face0 = __builtin_amdgcn_readfirstlane(face);
             // The shadow factor multiplies a product whose last factor is N.L; where N.L is zero in
             // every lane the result is the same zero (or NaN) whatever the taps say, so a wave that
             // faces away from the light skips them.
-            int count = 0;
+            float count = 0.0f;
             if (!__any(covered && NdotL > 0.0f)) {
             } else if (face0 >= 0 && __all(face == face0)) {
                 const float *fb = cube + (size_t)face0 * face_stride;
@@ -420,13 +467,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
                 else if (face0 >= 2) count = taps_one_face<1, TILED, POW2>(fb, p.cube_res, X, Y, Z, neg, cur);
                 else count = taps_one_face<0, TILED, POW2>(fb, p.cube_res, X, Y, Z, neg, cur);
             } else {
-                count = taps_any_face<TILED, POW2>(cube, p.cube_res, X, Y, Z, cur);
+                count = (float)taps_any_face<TILED, POW2>(cube, p.cube_res, X, Y, Z, cur);
             }
             const f3 Hv = add3(V, L);
-            float hlen, inv_hlen;
-            sqrt_and_rcp_rn(dot3(Hv, Hv), hlen, inv_hlen);
+            const float hlen2 = dot3(Hv, Hv);  // at most about 4: only the lower end of the fast domain needs a test
+            float inv_hlen;
+            if (__builtin_expect(!(hlen2 >= 0x1p-96f), 0)) inv_hlen = 1.0f / __builtin_sqrtf(hlen2);
+            else inv_hlen = fast_rcp_rn(fast_sqrt_rn(hlen2));
             const f3 H = scale3(Hv, inv_hlen);
-            const float att = rcp_rn_checked(dist * dist);
             // the denominators below lie in [1e-4, 8]: well inside fast_rcp_rn's exact domain
             const float D = normal_distribution(dot3(N, H), a2, rcp_fast);
             const float G = g1V * geometry_schlick(NdotL, k, omk, rcp_fast);
@@ -434,7 +482,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             const float isd = fast_rcp_rn(fma_(fourNdotV, NdotL, 0.0001f));
             const float DG = D * G;
 
-            const float lit = 1.0f - (float)count * (1.0f / 20.0f);
+            const float lit = 1.0f - count * (1.0f / 20.0f);
 
             const float o0 = ((fma_((1.0f - F.x) * albedo.x, INV_PI, (DG * F.x) * isd) * (lc.x * att)) * lit) * NdotL;
             const float o1 = ((fma_((1.0f - F.y) * albedo.y, INV_PI, (DG * F.y) * isd) * (lc.y * att)) * lit) * NdotL;
