@@ -231,6 +231,7 @@ VKR_DEV int taps_any_face(const float *cube, int res, const float (&X)[3], const
 {
     const float fres = (float)res;
     const unsigned face_bytes = (unsigned)res * (unsigned)res * 4u;
+    const unsigned face_shift = 2u * (unsigned)__builtin_ctz((unsigned)res) + 2u;  // POW2: face_bytes = 1 << face_shift
     const char *base = (const char *)cube;
     int count = 0;
     // "c >= 0 ? v : -v" is v ^ sign(c) (they differ only for c = -0, which can be the major
@@ -250,7 +251,7 @@ VKR_DEV int taps_any_face(const float *cube, int res, const float (&X)[3], const
         const float sc = zm ? scz : (ym ? rx : scx);                                               \
         const float tc = ym ? tcy : -ry;                                                           \
         const unsigned face = (zm ? 4u : (ym ? 2u : 0u)) | smaj;                                   \
-        const unsigned off = face * face_bytes + row_bytes<TILED>(face_texel<POW2>(tc, ima, fres, res), (unsigned)res) \
+        const unsigned off = (POW2 ? face << face_shift : face * face_bytes) + row_bytes<TILED>(face_texel<POW2>(tc, ima, fres, res), (unsigned)res) \
                              + col_bytes<TILED>(face_texel<POW2>(sc, ima, fres, res));                   \
         const float closest = *(const float *)(base + off) * 25.0f;                                \
         count += cur > closest ? 1 : 0;                                                            \
@@ -265,33 +266,38 @@ VKR_DEV int taps_any_face(const float *cube, int res, const float (&X)[3], const
     return count;
 }
 
-// Which single cube face all 27 combinations of {v-r, v, v+r}^3 select, or -1 if they do not
-// agree.  The comparisons are those of the face-selection rule (ties: z over y over x) applied to
-// the extreme candidates, so "agree" here implies the per-tap rule picks that face for each tap.
-VKR_DEV int common_face(const float (&X)[3], const float (&Y)[3], const float (&Z)[3])
+// Wave votes on a condition that is already a lane mask (HIP's __all / __any go through an integer select
+// and a second compare).
+VKR_DEV bool wave_all(bool c) { return __builtin_amdgcn_ballot_w64(c) == __builtin_amdgcn_ballot_w64(true); }
+VKR_DEV bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
+
+// The single cube face that all 27 combinations of {v-r, v, v+r}^3 select in every active lane of the
+// wave, or -1 if there is none.  (fx, fy, fz) is the centre direction v, r the disk radius.  The largest
+// magnitude of a coordinate's three candidates is |v| + r and, once |v| > r, the smallest is |v| - r, both
+// with the very rounding of the candidates themselves; the comparisons are those of the face-selection
+// rule (ties: z over y over x) on these extremes, so agreement here implies the per-tap rule picks the
+// face for each tap.  The major coordinate must also win by a margin (factor 1 - 2^-20): the one-face path
+// then needs no clamp of its texel coordinates (face_texel_inside), and since the other coordinates' maxima
+// are at least r > 0 the major one keeps its sign over its candidates and stays far inside fast_rcp_rn's
+// domain.  Decided with wave-wide votes: no per-lane selects.
+VKR_DEV int wave_common_face(float fx, float fy, float fz, float r)
 {
-    // X[0] <= X[1] <= X[2], so the largest magnitude is at an end; the third operand of the maximum keeps a
-    // winning major coordinate at 2^-100 or more, inside the domain of fast_rcp_rn
-    constexpr float TINY = 0x1p-100f;
-    const float xmin = __builtin_fminf(__builtin_fabsf(X[0]), __builtin_fminf(__builtin_fabsf(X[1]), __builtin_fabsf(X[2])));
-    const float xmax = __builtin_fmaxf(__builtin_fabsf(X[0]), __builtin_fmaxf(TINY, __builtin_fabsf(X[2])));
-    const float ymin = __builtin_fminf(__builtin_fabsf(Y[0]), __builtin_fminf(__builtin_fabsf(Y[1]), __builtin_fabsf(Y[2])));
-    const float ymax = __builtin_fmaxf(__builtin_fabsf(Y[0]), __builtin_fmaxf(TINY, __builtin_fabsf(Y[2])));
-    const float zmin = __builtin_fminf(__builtin_fabsf(Z[0]), __builtin_fminf(__builtin_fabsf(Z[1]), __builtin_fabsf(Z[2])));
-    const float zmax = __builtin_fmaxf(__builtin_fabsf(Z[0]), __builtin_fmaxf(TINY, __builtin_fabsf(Z[2])));
-    // The major coordinate must win by a margin (factor 1 - 2^-20): the one-face path then needs no clamp
-    // of its texel coordinates (face_texel_inside); combinations nearer a tie take the per-tap path.
+    const float ax = __builtin_fabsf(fx), ay = __builtin_fabsf(fy), az = __builtin_fabsf(fz);
+    const float xhi = ax + r, yhi = ay + r, zhi = az + r;
     constexpr float K = 1.0f - 0x1p-20f;
-    const float xs = xmin * K, ys = ymin * K, zs = zmin * K;
-    const bool zm = (zs >= xmax) & (zs >= ymax);       // z major for every combination
-    const bool ym = (zmax < ys) & (ys >= xmax);        // never z major, always y over x
-    const bool xm = (zmax < xs) & (ymax < xs);         // never z major, never y over x
-    // the major coordinate keeps one sign over its three candidates exactly when the smallest
-    // magnitude is not produced by a sign change, i.e. when v-r and v+r have the same sign
-    const float lo = zm ? Z[0] : (ym ? Y[0] : X[0]), hi = zm ? Z[2] : (ym ? Y[2] : X[2]);
-    const bool pos = lo >= 0.0f, neg = hi < 0.0f;      // lo <= mid <= hi
-    const int face = (zm ? 4 : (ym ? 2 : 0)) + (neg ? 1 : 0);
-    return ((zm | ym | xm) & (pos | neg)) ? face : -1;
+    const float xs = (ax - r) * K, ys = (ay - r) * K, zs = (az - r) * K;
+    // each comparison goes into its own ballot and the masks are combined as scalars: a ballot of a combined
+    // condition is compiled as a select and a second compare
+    const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
+    auto all2 = [active](bool a, bool b) { return (__builtin_amdgcn_ballot_w64(a) & __builtin_amdgcn_ballot_w64(b)) == active; };
+    int axis;
+    float major;
+    if (all2(zs >= xhi, zs >= yhi)) { axis = 4; major = fz; }        // z major for every combination
+    else if (all2(zhi < ys, ys >= xhi)) { axis = 2; major = fy; }    // never z major, always y over x
+    else if (all2(zhi < xs, yhi < xs)) { axis = 0; major = fx; }     // never z major, never y over x
+    else return -1;
+    const unsigned long long neg = __builtin_amdgcn_ballot_w64(major < 0.0f);
+    return neg == 0ull ? axis : (neg == active ? axis + 1 : -1);
 }
 
 // Workgroups are dealt to the 8 XCDs round-robin by id, and each XCD has its own L2.  This maps
@@ -314,13 +320,13 @@ VKR_DEV void tile_of_block(unsigned b, int tiles_x, int tiles_y, int &tx, int &t
     tx = (int)(cb * CB + r % cbw);
 }
 
-// Six waves per SIMD (80 VGPRs): the ten values the register allocator spills for that are used
-// only before and after the light loop, which itself touches no scratch memory.  Measured at
-// 4K / 64 lights: 4 waves 5.5 ms, 5 waves 4.6, 6 waves 4.5, 7 waves (spills inside the loop) 4.6.
+// Five waves per SIMD (96 VGPRs, none spilled).  Measured at 4K / 64 lights with this loop: 5 waves 3.74 ms,
+// 6 waves (80 VGPRs, one value reloaded from scratch memory per light) 3.77 ms; an earlier, longer loop
+// measured 4 waves 5.5 ms, 5 waves 4.6, 6 waves 4.5, 7 waves (spills inside the loop) 4.6.
 // MASKED: each light's draw touches only the pixels its light volume covers (one 64-bit mask per
 // light and tile, bit = lane); a light that covers none of the wave's pixels is skipped whole.
 template <bool TILED, bool POW2, bool MASKED>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void shade_kernel(const ShadeParams p)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void shade_kernel(const ShadeParams p)
 {
     // one wave per workgroup, one 8x8-pixel tile per wave
     const int lane = threadIdx.x;
@@ -426,17 +432,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
                 lc_next = mk3(lf[20], lf[21], lf[22]);
             }
             bool covered = true;
+            unsigned long long cover_mask = ~0ull;
             if (MASKED) {
-                const unsigned long long m = cover_c[(size_t)li * tiles + tile];  // wave-uniform: a scalar load
-                if (m == 0) continue;
-                covered = (m >> lane) & 1ull;
+                cover_mask = cover_c[(size_t)li * tiles + tile];  // wave-uniform: a scalar load
+                if (cover_mask == 0) continue;
+                covered = (cover_mask >> lane) & 1ull;
             }
             // fragToLight = pos - lp; L is its negation normalised (a - b = -(b - a) bit for bit, and the
             // squares in the length are the same)
             const f3 Fv = sub3(pos, lp);
             const float dist2 = dot3(Fv, Fv);
             float dist, inv_dist, att;
-            if (__builtin_expect(!(dist2 >= 0x1p-96f && dist2 <= 0x1p96f), 0)) {
+            const bool slow_domain = !(dist2 >= 0x1p-96f && dist2 <= 0x1p96f);
+            if (__builtin_expect(slow_domain, 0)) {
                 dist = __builtin_sqrtf(dist2);
                 inv_dist = 1.0f / dist;
                 att = 1.0f / (dist * dist);
@@ -453,14 +461,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             const float Y[3] = {Fv.y - disk, Fv.y, Fv.y + disk};
             const float Z[3] = {Fv.z - disk, Fv.z, Fv.z + disk};
             const float *cube = p.cube_shadow + (size_t)li * 6 * face_stride;
-            const int face = common_face(X, Y, Z);
-            const int face0 = __builtin_amdgcn_readfirstlane(face);
-            // The shadow factor multiplies a product whose last factor is N.L; where N.L is zero in
-            // every lane the result is the same zero (or NaN) whatever the taps say, so a wave that
-            // faces away from the light skips them.
-            float count = 0.0f;
-            if (!__any(covered && NdotL > 0.0f)) {
-            } else if (face0 >= 0 && __all(face == face0)) {
+            // The shadow factor multiplies a product whose last factor is N.L; where N.L is zero the result is the
+            // same zero whatever the taps say (the other factors are finite inside the fast domain, given finite
+            // G-buffer values and light colours), and adding it leaves both targets as they are: a wave that
+            // faces away from the light is done.  Masks of single comparisons are combined as scalars.
+            unsigned long long live = __builtin_amdgcn_ballot_w64(slow_domain) | __builtin_amdgcn_ballot_w64(NdotL > 0.0f);
+            if (MASKED) live &= cover_mask;
+            if (live == 0ull) continue;
+            const int face0 = wave_common_face(Fv.x, Fv.y, Fv.z, disk);
+            float count;
+            if (face0 >= 0) {
                 const float *fb = cube + (size_t)face0 * face_stride;
                 const bool neg = face0 & 1;
                 if (face0 >= 4) count = taps_one_face<2, TILED, POW2>(fb, p.cube_res, X, Y, Z, neg, cur);
@@ -469,6 +479,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             } else {
                 count = (float)taps_any_face<TILED, POW2>(cube, p.cube_res, X, Y, Z, cur);
             }
+            // all 20 taps in shadow: the factor 1 - 20/20 is an exact zero, same argument
+            if ((live & (__builtin_amdgcn_ballot_w64(slow_domain) | __builtin_amdgcn_ballot_w64(count < 20.0f))) == 0ull) continue;
             const f3 Hv = add3(V, L);
             const float hlen2 = dot3(Hv, Hv);  // at most about 4: only the lower end of the fast domain needs a test
             float inv_hlen;
@@ -487,13 +499,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             const float o0 = ((fma_((1.0f - F.x) * albedo.x, INV_PI, (DG * F.x) * isd) * (lc.x * att)) * lit) * NdotL;
             const float o1 = ((fma_((1.0f - F.y) * albedo.y, INV_PI, (DG * F.y) * isd) * (lc.y * att)) * lit) * NdotL;
             const float o2 = ((fma_((1.0f - F.z) * albedo.z, INV_PI, (DG * F.z) * isd) * (lc.z * att)) * lit) * NdotL;
-            const bool bright = covered && luminance(o0, o1, o2) > 1.0f;  // light.frag:78-82
+            const bool over = luminance(o0, o1, o2) > 1.0f;  // light.frag:78-82
+            const bool bright = covered && over;
             if (MASKED) {  // an uncovered pixel is not part of this draw: its targets keep their bits
                 c0 = covered ? round_f16(c0 + o0) : c0; c1 = covered ? round_f16(c1 + o1) : c1; c2 = covered ? round_f16(c2 + o2) : c2;
             } else {
                 c0 = round_f16(c0 + o0); c1 = round_f16(c1 + o1); c2 = round_f16(c2 + o2);
             }
-            if (__any(bright)) {  // adding 0 to the thresholded target changes nothing
+            if ((__builtin_amdgcn_ballot_w64(over) & cover_mask) != 0ull) {  // adding 0 to the thresholded target changes nothing
                 t0 = round_f16(t0 + (bright ? o0 : 0.0f));
                 t1 = round_f16(t1 + (bright ? o1 : 0.0f));
                 t2 = round_f16(t2 + (bright ? o2 : 0.0f));
