@@ -222,48 +222,94 @@ VKR_DEV float taps_one_face(const float *face_base, int res, const float (&X)[3]
     return count + count_a;  // an integer in [0, 20], exact in binary32
 }
 
-// The same count with the cube face chosen per tap and per lane (light.frag:133 through
-// shadowSampler: NEAREST on the face the direction's major axis selects).  This path runs for
-// the few waves that straddle a face edge; it recomputes everything per tap so that it needs no
-// more registers than the one-face path, which sets the kernel's occupancy.
-template <bool TILED, bool POW2>
-VKR_DEV int taps_any_face(const float *cube, int res, const float (&X)[3], const float (&Y)[3], const float (&Z)[3], float cur)
+// The count for a wave that straddles a cube edge or corner: the face is chosen per tap and per lane
+// (light.frag:133 through shadowSampler: NEAREST on the face the direction's major axis selects; ties go
+// to z over y over x).  One axis after the other gets the column / row tables of the one-face path (with
+// the clamp of the general rule and the face's base offset folded into the columns), so only one set of
+// tables is live; the twenty byte offsets start as those of the x faces, are replaced per lane and tap
+// by those of the y faces where |y| >= |x|, then by those of the z faces where |z| >= |x| and |z| >= |y|,
+// which is the selection rule.  All twenty loads are then in flight together as in the one-face path: the
+// memory latency, not the instruction count, is what a tap-by-tap formulation waits for.  An axis that is
+// the major one for no tap of the wave (two of three in a wave on one edge) is skipped: its offsets would
+// be replaced or never selected.  Dividing by the signed major coordinate applies the sign rule of the
+// face coordinates: sc = x/z, -z/x or x/|y|, tc = -y/|z|, -y/|x| or z/y ("c >= 0 ? v : -v" and v * sign(c)
+// differ only for c = -0, which can be the major coordinate only when the whole direction is zero).
+template <int AXIS, bool TILED, bool POW2, typename EMIT>
+VKR_DEV void tap_offsets_of_axis(int res, unsigned face_shift, const float (&X)[3], const float (&Y)[3], const float (&Z)[3], EMIT emit)
 {
     const float fres = (float)res;
-    const unsigned face_bytes = (unsigned)res * (unsigned)res * 4u;
-    const unsigned face_shift = 2u * (unsigned)__builtin_ctz((unsigned)res) + 2u;  // POW2: face_bytes = 1 << face_shift
-    const char *base = (const char *)cube;
-    int count = 0;
-    // "c >= 0 ? v : -v" is v ^ sign(c) (they differ only for c = -0, which can be the major
-    // coordinate only when the whole direction is zero)
-#define VKR_TAP(gx, gy, gz)                                                                        \
-    {                                                                                              \
-        const float rx = X[gx], ry = Y[gy], rz = Z[gz];                                            \
-        const float ax = __builtin_fabsf(rx), ay = __builtin_fabsf(ry), az = __builtin_fabsf(rz);  \
-        const unsigned bx = __builtin_bit_cast(unsigned, rx), by = __builtin_bit_cast(unsigned, ry), bz = __builtin_bit_cast(unsigned, rz); \
-        const bool zm = (az >= ax) & (az >= ay);                                                   \
-        const bool ym = !zm & (ay >= ax);                                                          \
-        const float ima = fast_rcp_rn(zm ? az : (ym ? ay : ax));                                   \
-        const unsigned smaj = (zm ? bz : (ym ? by : bx)) >> 31;                                    \
-        const float scz = __builtin_bit_cast(float, bx ^ (bz & 0x80000000u));                      \
-        const float scx = __builtin_bit_cast(float, bz ^ (~bx & 0x80000000u));                     \
-        const float tcy = __builtin_bit_cast(float, bz ^ (by & 0x80000000u));                      \
-        const float sc = zm ? scz : (ym ? rx : scx);                                               \
-        const float tc = ym ? tcy : -ry;                                                           \
-        const unsigned face = (zm ? 4u : (ym ? 2u : 0u)) | smaj;                                   \
-        const unsigned off = (POW2 ? face << face_shift : face * face_bytes) + row_bytes<TILED>(face_texel<POW2>(tc, ima, fres, res), (unsigned)res) \
-                             + col_bytes<TILED>(face_texel<POW2>(sc, ima, fres, res));                   \
-        const float closest = *(const float *)(base + off) * 25.0f;                                \
-        count += cur > closest ? 1 : 0;                                                            \
+    const float (&M)[3] = AXIS == 2 ? Z : (AXIS == 1 ? Y : X);
+    float R[3];        // RN(1 / major coordinate), signed
+    unsigned B[3];     // byte offset of the face each major candidate selects
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        R[k] = fast_rcp_rn(M[k]);
+        const unsigned face = (unsigned)(AXIS * 2) | (__builtin_bit_cast(unsigned, M[k]) >> 31);
+        B[k] = POW2 ? face << face_shift : face * ((unsigned)res * (unsigned)res * 4u);
     }
-#define VKR_FENCE asm volatile("" : "+v"(count));  /* at most five loads in flight */
-    VKR_TAP(2, 2, 2) VKR_TAP(2, 0, 2) VKR_TAP(0, 0, 2) VKR_TAP(0, 2, 2) VKR_TAP(2, 2, 0) VKR_FENCE
-    VKR_TAP(2, 0, 0) VKR_TAP(0, 0, 0) VKR_TAP(0, 2, 0) VKR_TAP(2, 2, 1) VKR_TAP(2, 0, 1) VKR_FENCE
-    VKR_TAP(0, 0, 1) VKR_TAP(0, 2, 1) VKR_TAP(2, 1, 2) VKR_TAP(0, 1, 2) VKR_TAP(2, 1, 0) VKR_FENCE
-    VKR_TAP(0, 1, 0) VKR_TAP(1, 2, 2) VKR_TAP(1, 0, 2) VKR_TAP(1, 0, 0) VKR_TAP(1, 2, 0)
-#undef VKR_FENCE
+    unsigned I[3][3], J[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+            if (a == 1 && m == 1) { I[a][m] = 0; J[a][m] = 0; continue; }  // no tap uses (v, v)
+            const float rs = R[m], ru = __builtin_fabsf(R[m]);
+            float u, ur, w, wr;
+            if (AXIS == 2) { u = X[a]; ur = rs; w = -Y[a]; wr = ru; }
+            else if (AXIS == 1) { u = X[a]; ur = ru; w = Z[a]; wr = rs; }
+            else { u = -Z[a]; ur = rs; w = -Y[a]; wr = ru; }
+            I[a][m] = col_bytes<TILED>(face_texel<POW2>(u, ur, fres, res)) + B[m];
+            J[a][m] = row_bytes<TILED>(face_texel<POW2>(w, wr, fres, res), (unsigned)res);
+        }
+    int k = 0;
+#define VKR_TAP(gx, gy, gz)                                                              \
+    {                                                                                    \
+        constexpr int iu = AXIS == 0 ? gz : gx, iw = AXIS == 1 ? gz : gy, im = AXIS == 2 ? gz : (AXIS == 1 ? gy : gx); \
+        emit(k++, gx, gy, gz, J[iw][im] + I[iu][im]);                                    \
+    }
+    VKR_GRID20(VKR_TAP)
 #undef VKR_TAP
-    return count;
+}
+
+template <bool TILED, bool POW2>
+VKR_DEV float taps_any_face(const float *cube, int res, const float (&X)[3], const float (&Y)[3], const float (&Z)[3], float cur,
+                            bool has_x, bool has_y, bool has_z)
+{
+    const unsigned face_shift = 2u * (unsigned)__builtin_ctz((unsigned)res) + 2u;  // POW2: bytes per face = 1 << face_shift
+    const char *base = (const char *)cube;
+    unsigned off[20];
+#pragma unroll
+    for (int k = 0; k < 20; k++) off[k] = 0u;
+    if (has_x)
+        tap_offsets_of_axis<0, TILED, POW2>(res, face_shift, X, Y, Z, [&](int k, int, int, int, unsigned o) { off[k] = o; });
+    if (has_y)
+        tap_offsets_of_axis<1, TILED, POW2>(res, face_shift, X, Y, Z, [&](int k, int gx, int gy, int, unsigned o) {
+            off[k] = __builtin_fabsf(Y[gy]) >= __builtin_fabsf(X[gx]) ? o : off[k];
+        });
+    if (has_z)
+        tap_offsets_of_axis<2, TILED, POW2>(res, face_shift, X, Y, Z, [&](int k, int gx, int gy, int gz, unsigned o) {
+            const float az = __builtin_fabsf(Z[gz]);
+            off[k] = ((az >= __builtin_fabsf(X[gx])) & (az >= __builtin_fabsf(Y[gy]))) ? o : off[k];
+        });
+    const float cur_s = cur * 0x1p60f;
+    float count_a = 0.0f, count_b = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 10; k++) count_a += step_closer(*(const float *)(base + off[k]) * 25.0f, cur_s);
+#pragma unroll
+    for (int k = 10; k < 20; k++) count_b += step_closer(*(const float *)(base + off[k]) * 25.0f, cur_s);
+    return count_a + count_b;
+}
+
+// Which axes can be the major one for some tap of some active lane, as bits 0 (x), 1 (y), 2 (z).  An axis
+// never is where its largest candidate magnitude |v| + r stays below the smallest |v| - r of another
+// axis (which of the two others may differ from lane to lane).
+VKR_DEV unsigned wave_major_axes(float fx, float fy, float fz, float r)
+{
+    const float ax = __builtin_fabsf(fx), ay = __builtin_fabsf(fy), az = __builtin_fabsf(fz);
+    const float xhi = ax + r, yhi = ay + r, zhi = az + r, xlo = ax - r, ylo = ay - r, zlo = az - r;
+    const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
+    auto either = [active](bool a, bool b) { return (__builtin_amdgcn_ballot_w64(a) | __builtin_amdgcn_ballot_w64(b)) == active; };
+    return (either(xhi < zlo, xhi < ylo) ? 0u : 1u) | (either(yhi < zlo, yhi < xlo) ? 0u : 2u) | (either(zhi < ylo, zhi < xlo) ? 0u : 4u);
 }
 
 // Wave votes on a condition that is already a lane mask (HIP's __all / __any go through an integer select
@@ -476,8 +522,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                 if (face0 >= 4) count = taps_one_face<2, TILED, POW2>(fb, p.cube_res, X, Y, Z, neg, cur);
                 else if (face0 >= 2) count = taps_one_face<1, TILED, POW2>(fb, p.cube_res, X, Y, Z, neg, cur);
                 else count = taps_one_face<0, TILED, POW2>(fb, p.cube_res, X, Y, Z, neg, cur);
-            } else {
-                count = (float)taps_any_face<TILED, POW2>(cube, p.cube_res, X, Y, Z, cur);
+            } else {  // the wave straddles a cube edge or corner
+                const unsigned axes = wave_major_axes(Fv.x, Fv.y, Fv.z, disk);
+                count = taps_any_face<TILED, POW2>(cube, p.cube_res, X, Y, Z, cur, axes & 1u, axes & 2u, axes & 4u);
             }
             // all 20 taps in shadow: the factor 1 - 20/20 is an exact zero, same argument
             if ((live & (__builtin_amdgcn_ballot_w64(slow_domain) | __builtin_amdgcn_ballot_w64(count < 20.0f))) == 0ull) continue;
