@@ -173,18 +173,17 @@ VKR_DEV float step_closer(float closest, float cur_s)
 }
 
 // Number of the 20 taps whose stored depth is closer than `cur` when every tap of every lane of
-// the wave lies on cube face `face` (wave-uniform).  U, W are the coordinates that become sc, tc
-// (sign already applied), IM the reciprocals of |major coordinate|; the index triple of a tap is
-// permuted so that (iu, iw, im) index U, W, IM.
+// the wave lies on one cube face of axis AXIS (`face_base` points at it).  The index triple of a tap is
+// permuted so that (iu, iw, im) index the coordinates that become sc and tc and the major coordinate.
 template <int AXIS, bool TILED, bool POW2>
-VKR_DEV float taps_one_face(const float *face_base, int res, const float (&X)[3], const float (&Y)[3], const float (&Z)[3], bool neg, float cur)
+VKR_DEV float taps_one_face(const float *face_base, int res, const float (&X)[3], const float (&Y)[3], const float (&Z)[3], float cur)
 {
     const float fres = (float)res;
     const float (&M)[3] = AXIS == 2 ? Z : (AXIS == 1 ? Y : X);
-    float IM[3];
+    float R[3];  // RN(1 / major coordinate), signed: dividing by it applies the sign rule of the face coordinates
 #pragma unroll
-    for (int k = 0; k < 3; k++) IM[k] = fast_rcp_rn(__builtin_fabsf(M[k]));
-    // z major: sc = +-x, tc = -y;  y major: sc = x, tc = +-z;  x major: sc = -+z, tc = -y
+    for (int k = 0; k < 3; k++) R[k] = fast_rcp_rn(M[k]);
+    // z major: sc = x/z, tc = -y/|z|;  y major: sc = x/|y|, tc = z/y;  x major: sc = -z/x, tc = -y/|x|
     // column offset in bytes, row offset in units of 32 bytes (tiled: (j>>2) * (res/8 tiles * 4) + j) or of
     // one row (row-major); [index into U / W][index into M]
     unsigned I[3][3], J[3][3];
@@ -194,12 +193,13 @@ VKR_DEV float taps_one_face(const float *face_base, int res, const float (&X)[3]
 #pragma unroll
         for (int m = 0; m < 3; m++) {
             if (a == 1 && m == 1) { I[a][m] = 0; J[a][m] = 0; continue; }  // no tap uses (v, v)
-            float u, w;
-            if (AXIS == 2) { u = neg ? -X[a] : X[a]; w = -Y[a]; }
-            else if (AXIS == 1) { u = X[a]; w = neg ? -Z[a] : Z[a]; }
-            else { u = neg ? Z[a] : -Z[a]; w = -Y[a]; }
-            I[a][m] = col_bytes<TILED>(face_texel_inside<POW2>(u, IM[m], fres));
-            const unsigned j = (unsigned)face_texel_inside<POW2>(w, IM[m], fres);
+            const float rs = R[m], ru = __builtin_fabsf(R[m]);
+            float u, ur, w, wr;
+            if (AXIS == 2) { u = X[a]; ur = rs; w = -Y[a]; wr = ru; }
+            else if (AXIS == 1) { u = X[a]; ur = ru; w = Z[a]; wr = rs; }
+            else { u = -Z[a]; ur = rs; w = -Y[a]; wr = ru; }
+            I[a][m] = col_bytes<TILED>(face_texel_inside<POW2>(u, ur, fres));
+            const unsigned j = (unsigned)face_texel_inside<POW2>(w, wr, fres);
             J[a][m] = TILED ? __umul24(j >> 2, ((unsigned)res >> 1) - 4u) + j : j;
         }
     const float cur_s = cur * 0x1p60f;
@@ -518,10 +518,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             float count;
             if (face0 >= 0) {
                 const float *fb = cube + (size_t)face0 * face_stride;
-                const bool neg = face0 & 1;
-                if (face0 >= 4) count = taps_one_face<2, TILED, POW2>(fb, p.cube_res, X, Y, Z, neg, cur);
-                else if (face0 >= 2) count = taps_one_face<1, TILED, POW2>(fb, p.cube_res, X, Y, Z, neg, cur);
-                else count = taps_one_face<0, TILED, POW2>(fb, p.cube_res, X, Y, Z, neg, cur);
+                if (face0 >= 4) count = taps_one_face<2, TILED, POW2>(fb, p.cube_res, X, Y, Z, cur);
+                else if (face0 >= 2) count = taps_one_face<1, TILED, POW2>(fb, p.cube_res, X, Y, Z, cur);
+                else count = taps_one_face<0, TILED, POW2>(fb, p.cube_res, X, Y, Z, cur);
             } else {  // the wave straddles a cube edge or corner
                 const unsigned axes = wave_major_axes(Fv.x, Fv.y, Fv.z, disk);
                 count = taps_any_face<TILED, POW2>(cube, p.cube_res, X, Y, Z, cur, axes & 1u, axes & 2u, axes & 4u);
