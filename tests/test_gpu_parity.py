@@ -888,3 +888,28 @@ def test_fast_reciprocal_and_square_root_are_correctly_rounded(gpu):
     assert n_rcp > 4.2e9 and n_sqrt > 2.1e9
     assert (rcp1, sqrt_, rcp_of_sqrt) == (0, 0, 0)
     assert pair == 0
+
+
+def test_shade_lights_on_cube_edges_corners_and_surfaces(gpu, oracle):
+    """Lights placed so that many pixels see them along cube edges and corners (|x| = |y| = |z| directions), a
+    hand's breadth above the surface (every tap on another face), and exactly on a pixel's position
+    (distance zero: the slow branches of the reciprocal and the root)."""
+    torch, P = _torch(), _passes()
+    w, h, nl, cube = 128, 72, 8, 32
+    f = synth.make_frame(97, w, h, nl, cube, 64, irr_res=8, pref_res=16, lut_res=32)
+    pos = oracle.f16_to_f32(f.position)[..., :3]
+    lights = f.lights.copy()
+    anchors = [(10, 20), (40, 64), (60, 100), (30, 30), (50, 90), (20, 110), (65, 5), (5, 70)]
+    offsets = [(0.7, 0.7, 0.7), (-0.5, 0.5, 0.5), (0.6, 0.6, 0.0), (0.0, -0.4, 0.4), (0.02, 0.03, 0.01), (0.0, 0.0, 0.0),
+               (1.5, 1.5, -1.5), (0.3, 0.0, 0.3)]
+    for i, ((y, x), o) in enumerate(zip(anchors, offsets)):
+        lights["position"][i] = pos[y, x] + np.asarray(o, dtype=np.float32)
+    f.lights = lights
+    want_c, want_t = oracle.shade(f)
+    for tiled in (True, False):
+        d = P.DeviceFrame.upload(f, gpu, tiled=tiled)
+        color = torch.empty((h, w, 4), dtype=torch.float16, device=gpu)
+        thr = torch.empty_like(color)
+        P.shade(d, color, thr)
+        assert_bits_equal(P.f16_bits(color), want_c, f"colour (tiled cubes: {tiled})")
+        assert_bits_equal(P.f16_bits(thr), want_t, f"threshold (tiled cubes: {tiled})")
