@@ -810,6 +810,21 @@ static int shadow_bbox(const float (*c)[4], int res, int *bx0, int *by0, int *bx
 
 /* Rasterises one triangle into one res x res depth image.  clip: the three clip-space corners;
  * world: their world positions (point lights) or NULL (directional: fixed-function depth). */
+/* point_shadow.frag:11-16 */
+static float point_shadow_depth(const float *p, const float *light_pos, float inv_far)
+{
+    v3 d = v3_(p[0] - light_pos[0], p[1] - light_pos[1], p[2] - light_pos[2]);
+    return sqrtf(dot3(d, d)) * inv_far;
+}
+
+/* point_shadow.vert:12 (world = model * pos) and point_shadow.geom:19-20 (clip = shadowMatrices[face] * world) */
+static void point_shadow_vertex(const float *model, const float *face_matrix, const float *pos3, float *world4, float *clip4)
+{
+    const float v4[4] = {pos3[0], pos3[1], pos3[2], 1.0f};
+    mat4_vec4(model, v4, world4);
+    mat4_vec4(face_matrix, world4, clip4);
+}
+
 static void shadow_raster(const float (*clip)[4], const float (*world)[4], const float *light_pos, float inv_far, int res, float *img)
 {
     cov_tri t;
@@ -831,8 +846,7 @@ static void shadow_raster(const float (*clip)[4], const float (*world)[4], const
                 float p[3];
                 for (int k = 0; k < 3; k++)
                     p[k] = (float)(fma(e2, (double)world[2][k], fma(e1, (double)world[1][k], e0 * (double)world[0][k])) / s);
-                v3 d = v3_(p[0] - light_pos[0], p[1] - light_pos[1], p[2] - light_pos[2]);
-                depth = sqrtf(dot3(d, d)) * inv_far;
+                depth = point_shadow_depth(p, light_pos, inv_far);
             } else {
                 depth = (float)(zs / t.D) + 0.0f; /* z / w of the fixed-function pipeline (-0 becomes +0) */
             }
@@ -859,10 +873,7 @@ ORC_API void orc_point_shadow_maps(const orc_point_shadow_args *a)
             for (int t = 0; t < dr->n_tris; t++) {
                 float world[3][4], clip[3][4];
                 for (int k = 0; k < 3; k++) {
-                    const float *v = dr->positions + 3 * (size_t)dr->indices[3 * t + k];
-                    const float v4[4] = {v[0], v[1], v[2], 1.0f};
-                    mat4_vec4(dr->model, v4, world[k]);   /* point_shadow.vert:12 */
-                    mat4_vec4(m, world[k], clip[k]);      /* point_shadow.geom:20 */
+                    point_shadow_vertex(dr->model, m, dr->positions + 3 * (size_t)dr->indices[3 * t + k], world[k], clip[k]);
                 }
                 shadow_raster(clip, world, lp, inv_far, a->res, img);
             }
@@ -891,6 +902,25 @@ ORC_API void orc_dir_shadow_map(const orc_dir_shadow_args *a)
 }
 
 ORC_API void orc_shadow_face_matrix(const float *eye, int face, float far_plane, float *out16) { shadow_face_matrix(eye, face, far_plane, out16); }
+
+/* Single invocations of the shadow passes' shaders, for the tests that pin them to the reference's binaries. */
+ORC_API void orc_point_shadow_vertex(const float *model, const float *face_matrix, const float *pos3, float *world4, float *clip4)
+{
+    point_shadow_vertex(model, face_matrix, pos3, world4, clip4);
+}
+
+ORC_API float orc_point_shadow_depth(const float *world3, const float *light_pos, float far_plane)
+{
+    return point_shadow_depth(world3, light_pos, rcpf_(far_plane));
+}
+
+ORC_API void orc_depth_vertex(const float *model, const float *light_space, const float *pos3, float *clip4)
+{
+    float mvp[16];
+    const float v4[4] = {pos3[0], pos3[1], pos3[2], 1.0f};
+    mat4_mul(model, light_space, mvp);  /* depth.vert:13, as orc_dir_shadow_map */
+    mat4_vec4(mvp, v4, clip4);
+}
 
 /* ------------------------------------------------------------------------------------------ */
 /* bloom_blur.frag:14-33.  wrap = REPEAT for pass 1 (reads the thresholded target through

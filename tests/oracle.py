@@ -394,3 +394,31 @@ def equirect_uv(d) -> np.ndarray:
     out = np.empty(2, dtype=np.float32)
     load().orc_equirect_uv(_p(d), _p(out))
     return out
+
+
+def point_shadow_vertex(model: np.ndarray, face_matrix: np.ndarray, pos: np.ndarray):
+    """point_shadow.vert + point_shadow.geom for one vertex and one face: (world [4], clip [4])."""
+    m = np.ascontiguousarray(model, dtype=np.float32).ravel()
+    fm = np.ascontiguousarray(face_matrix, dtype=np.float32).ravel()
+    p = np.ascontiguousarray(pos, dtype=np.float32)
+    world, clip = np.zeros(4, np.float32), np.zeros(4, np.float32)
+    load().orc_point_shadow_vertex(_p(m), _p(fm), _p(p), _p(world), _p(clip))
+    return world, clip
+
+
+def point_shadow_depth(world: np.ndarray, light_pos: np.ndarray, far_plane: float) -> float:
+    """point_shadow.frag for one fragment."""
+    lib = load()
+    lib.orc_point_shadow_depth.restype = C.c_float
+    w, l = np.ascontiguousarray(world, dtype=np.float32), np.ascontiguousarray(light_pos, dtype=np.float32)
+    return float(lib.orc_point_shadow_depth(_p(w), _p(l), C.c_float(far_plane)))
+
+
+def depth_vertex(model: np.ndarray, light_space: np.ndarray, pos: np.ndarray) -> np.ndarray:
+    """depth.vert for one vertex: clip position [4]."""
+    m = np.ascontiguousarray(model, dtype=np.float32).ravel()
+    ls = np.ascontiguousarray(light_space, dtype=np.float32).ravel()
+    p = np.ascontiguousarray(pos, dtype=np.float32)
+    clip = np.zeros(4, np.float32)
+    load().orc_depth_vertex(_p(m), _p(ls), _p(p), _p(clip))
+    return clip

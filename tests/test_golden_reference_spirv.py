@@ -132,3 +132,29 @@ def test_skybox_shaders(oracle):
         got = sky[px[:, 1], px[:, 0]]
         assert close(got, g["colour"][k]).all(), (k, np.abs(got - g["colour"][k]).max())
         assert (got[:, 3] == 1.0).all()
+
+
+def test_shadow_pass_shaders(oracle):
+    """point_shadow.vert / .geom / .frag and depth.vert.  The recorded cube-face matrices were built the way
+    System.Numerics builds them (look-at times perspective, float64, rounded once): the oracle's own (exact unit
+    axes, binary32 fmas) agree to a few ulps of the largest element; with the recorded matrices the oracle's
+    vertex path reproduces the geometry shader's clip positions."""
+    g = np.load(os.path.join(GOLDEN, "shadow.npz"))
+    light, far = g["light"], float(g["far"])
+    for face in range(6):
+        mine = oracle.shadow_face_matrix(light, face, far)
+        want = g["face_matrices"][face]
+        assert np.abs(mine.reshape(4, 4) - want).max() <= 4 * np.spacing(np.float32(np.abs(want).max())), face
+    for t in range(4):
+        for k in range(3):
+            for face in range(6):
+                world, clip = oracle.point_shadow_vertex(g["model"], g["face_matrices"][face], g["positions"][t, k])
+                assert np.allclose(world, g["world"][t, k], rtol=1e-6, atol=1e-6)
+                want = g["clip"][t, face, k]
+                assert np.abs(clip - want).max() <= 8 * np.spacing(np.float32(np.abs(want).max())), (t, k, face, clip, want)
+            clip = oracle.depth_vertex(g["model"], g["light_space"], g["positions"][t, k])
+            want = g["depth_clip"][t, k]
+            assert np.abs(clip - want).max() <= 8 * np.spacing(np.float32(max(np.abs(want).max(), 1.0))), (t, k, clip, want)
+    for p, want in zip(g["frag_pos"], g["frag_depth"]):
+        got = oracle.point_shadow_depth(p, light, far)
+        assert abs(got - want) <= 2 * np.spacing(np.float32(want)), (p, got, want)

@@ -284,6 +284,72 @@ def skybox_vectors(spv_dir):
     print("skybox vectors written")
 
 
+def shadow_vectors(spv_dir):
+    """The shadow passes' shaders: point_shadow.vert / .geom / .frag and depth.vert.  The six cube-face matrices
+    are built here in float64 the way System.Numerics builds them (CreateLookAt * CreatePerspectiveFieldOfView,
+    VulkanRenderer.cs:327-339) and rounded to float32: an independent restatement for the oracle's own."""
+    vs = Shader(os.path.join(spv_dir, "point_shadow.vert.spv"))
+    gs = Shader(os.path.join(spv_dir, "point_shadow.geom.spv"))
+    fs = Shader(os.path.join(spv_dir, "point_shadow.frag.spv"))
+    dv = Shader(os.path.join(spv_dir, "depth.vert.spv"))
+    rng = np.random.default_rng(61)
+    cols = lambda m: [np.asarray(r, dtype=np.float32) for r in np.asarray(m, dtype=np.float32).reshape(4, 4)]
+    light = np.array([0.7, 2.1, -0.4], dtype=np.float32)
+    far = np.float32(25.0)
+
+    def look_at(pos, target, up):
+        z = pos - target; z /= np.linalg.norm(z)
+        x = np.cross(up, z); x /= np.linalg.norm(x)
+        y = np.cross(z, x)
+        m = np.eye(4)
+        m[:3, 0], m[:3, 1], m[:3, 2] = x, y, z
+        m[3, :3] = (-x @ pos, -y @ pos, -z @ pos)
+        return m
+
+    def perspective(fov, aspect, near, farp):
+        ys = 1.0 / np.tan(fov / 2)
+        m = np.zeros((4, 4))
+        m[0, 0], m[1, 1] = ys / aspect, ys
+        m[2, 2], m[2, 3] = farp / (near - farp), -1.0
+        m[3, 2] = near * farp / (near - farp)
+        return m
+
+    proj = perspective(np.pi / 2, 1.0, 1.0, 25.0)
+    lp = light.astype(np.float64)
+    ux, uy, uz = np.eye(3)
+    faces = [(ux, -uy), (-ux, -uy), (uy, uz), (-uy, -uz), (uz, -uy), (-uz, -uy)]
+    mats = np.stack([(look_at(lp, lp + d, u) @ proj) for d, u in faces]).astype(np.float32)
+    ang = 0.5
+    rot = np.array([[np.cos(ang), np.sin(ang), 0, 0], [-np.sin(ang), np.cos(ang), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    model = np.diag([1.2, 0.8, 1.1, 1.0]) @ rot
+    model[3, :3] = (0.3, -0.5, 0.9)
+    model = model.astype(np.float32)
+    pos = rng.uniform(-3, 3, (4, 3, 3)).astype(np.float32)          # four triangles
+    world = np.zeros((4, 3, 4), np.float32)
+    clip = np.zeros((4, 6, 3, 4), np.float32)
+    for t in range(4):
+        for k in range(3):
+            world[t, k] = vs.run({0: pos[t, k]}, {"push": [cols(model)]})["out"]["builtin"][0]
+        gl_in = [[world[t, k], np.float32(1.0), [np.float32(0)], [np.float32(0)]] for k in range(3)]
+        gs.run({"gl_in": gl_in}, {(0, 0): [[cols(m) for m in mats]]})
+        emitted = [e for e in gs.emitted if e is not None]
+        assert len(emitted) == 18 and gs.emitted[3] is None
+        for n, e in enumerate(emitted):
+            face, k = divmod(n, 3)
+            assert int(e[("builtin", 9)]) == face                    # gl_Layer
+            assert np.array_equal(e[0], world[t, k])                 # the world position handed to the fragment shader
+            clip[t, face, k] = e["builtin"][0]
+    frag_pos = rng.uniform(-6, 6, (16, 3)).astype(np.float32)
+    frag_depth = np.array([fs.run({0: np.append(p, np.float32(1.0))}, {"push": [light, far]})["out"][("builtin", 22)] for p in frag_pos], dtype=np.float32)
+    light_space = (look_at(np.array([4.0, 9.0, 3.0]), np.zeros(3), uy) @ np.diag([0.1, 0.1, -0.05, 1.0])).astype(np.float32)
+    light_space[3, 2] += np.float32(0.5)
+    depth_clip = np.array([dv.run({0: p}, {"push": [cols(model), cols(light_space)]})["out"]["builtin"][0] for p in pos.reshape(-1, 3)], dtype=np.float32)
+    np.savez_compressed(os.path.join(OUT, "shadow.npz"), light=light, far=far, face_matrices=mats, model=model, positions=pos,
+                        world=world, clip=clip, frag_pos=frag_pos, frag_depth=frag_depth, light_space=light_space,
+                        depth_clip=depth_clip.reshape(4, 3, 4))
+    print("shadow vectors written")
+
+
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     spv = args[0] if args else "/root/reference/compiled_shaders"
@@ -293,8 +359,11 @@ if __name__ == "__main__":
         gpass_vectors(spv)
     elif "--only-skybox" in sys.argv:
         skybox_vectors(spv)
+    elif "--only-shadow" in sys.argv:
+        shadow_vectors(spv)
     else:
         main(spv)
         light_vert_vectors(spv)
         gpass_vectors(spv)
         skybox_vectors(spv)
+        shadow_vectors(spv)

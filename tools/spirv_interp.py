@@ -302,6 +302,9 @@ class Shader:
             if sc == 1:      # Input
                 if 11 in dec and dec[11][0] == 15:   # BuiltIn FragCoord
                     val = np.asarray(inputs["frag_coord"], dtype=np.float32)
+                elif 30 not in dec:                  # gl_in[] of a geometry shader: list of gl_PerVertex members
+                    self.globals[gid] = Pointer([inputs["gl_in"]])
+                    continue
                 else:
                     val = inputs[dec[30][0]]
                     t = m.types[pt[2]]
@@ -315,7 +318,8 @@ class Shader:
             elif sc == 3:    # Output
                 cell = [self._default(pt[2])]
                 self.globals[gid] = Pointer(cell)
-                outputs[dec[30][0] if 30 in dec else "builtin"] = cell  # no Location: the gl_PerVertex block
+                # no Location: the gl_PerVertex block, or a single built-in such as gl_Layer (BuiltIn 9)
+                outputs[dec[30][0] if 30 in dec else (("builtin", dec[11][0]) if 11 in dec else "builtin")] = cell
             elif sc == 2:    # Uniform (a uniform block: list of members, matrices as lists of columns)
                 self.globals[gid] = Pointer([list(resources[(dec[34][0], dec[33][0])])])
             elif sc == 0:    # UniformConstant (samplers)
@@ -326,6 +330,8 @@ class Shader:
                 init = m.const_value(g["init"]) if g["init"] is not None else self._default(pt[2])
                 self.globals[gid] = Pointer([init])
         killed = False
+        self.emitted = []          # geometry shaders: a copy of every output at each EmitVertex
+        self._outputs = outputs
         try:
             self._call(m.entry, [])
         except Kill:
@@ -463,6 +469,11 @@ class Shader:
                     break
                 elif op == 252:
                     raise Kill()
+                elif op == 218:    # OpEmitVertex
+                    import copy
+                    self.emitted.append({loc: copy.deepcopy(cell[0]) for loc, cell in self._outputs.items()})
+                elif op == 219:    # OpEndPrimitive
+                    self.emitted.append(None)
                 elif op == 253:
                     return None
                 elif op == 254:
