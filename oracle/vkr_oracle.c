@@ -832,6 +832,7 @@ static void shadow_raster(const float (*clip)[4], const float (*world)[4], const
     int bx0, by0, bx1, by1;
     if (!shadow_bbox(clip, res, &bx0, &by0, &bx1, &by1)) return;
     const double sc = 2.0 / (double)res;
+    const double inv_D = 1.0 / t.D;  /* one division per triangle */
     for (int j = by0; j <= by1; j++) {
         const double yn = fma((double)j + 0.5, sc, -1.0);
         for (int i = bx0; i <= bx1; i++) {
@@ -844,11 +845,12 @@ static void shadow_raster(const float (*clip)[4], const float (*world)[4], const
             float depth;
             if (world) { /* point_shadow.frag:11-16 on the interpolated world position */
                 float p[3];
+                const double inv_s = 1.0 / s;  /* one division per sample: sum(Ei * Pi) * (1 / sum(Ei)) */
                 for (int k = 0; k < 3; k++)
-                    p[k] = (float)(fma(e2, (double)world[2][k], fma(e1, (double)world[1][k], e0 * (double)world[0][k])) / s);
+                    p[k] = (float)(fma(e2, (double)world[2][k], fma(e1, (double)world[1][k], e0 * (double)world[0][k])) * inv_s);
                 depth = point_shadow_depth(p, light_pos, inv_far);
             } else {
-                depth = (float)(zs / t.D) + 0.0f; /* z / w of the fixed-function pipeline (-0 becomes +0) */
+                depth = (float)(zs * inv_D) + 0.0f; /* z / w of the fixed-function pipeline as z * (1/w) (-0 becomes +0) */
             }
             float *o = img + (size_t)j * res + i;
             if (depth < *o) *o = depth; /* CompareOp.Less, depth writes on */
@@ -1398,6 +1400,7 @@ ORC_API void orc_gbuffer(const orc_gpass_args *a)
                 if (by1 > a->rows - 1) by1 = a->rows - 1;
                 if (by0 > by1) continue;
             }
+            const double inv_D = 1.0 / tr.D;  /* one division per triangle: depth = z * (1/w) */
             for (int y = by0; y <= by1; y++) {
                 const double yn = fma((double)(a->row0 + y) + 0.5, sy, -1.0);
                 for (int x = bx0; x <= bx1; x++) {
@@ -1406,7 +1409,7 @@ ORC_API void orc_gbuffer(const orc_gpass_args *a)
                     if (!(e0 >= 0.0 && e1 >= 0.0 && e2 >= 0.0 && (e0 + e1) + e2 > 0.0)) continue;
                     const double zs = fma(e2, tr.z[2], fma(e1, tr.z[1], e0 * tr.z[0]));
                     if (!(zs >= 0.0 && zs <= tr.D)) continue;
-                    const float depth = (float)(zs / tr.D) + 0.0f;
+                    const float depth = (float)(zs * inv_D) + 0.0f;
                     uint32_t bits; memcpy(&bits, &depth, 4);
                     const uint64_t key = ((uint64_t)bits << 32) | (uint64_t)(base + (uint32_t)t);
                     uint64_t *o = vis + (size_t)y * a->width + x;
@@ -1441,8 +1444,8 @@ ORC_API void orc_gbuffer(const orc_gpass_args *a)
             for (int i = 0; i < 3; i++) { tr.a[i] = -tr.a[i]; tr.b[i] = -tr.b[i]; tr.c[i] = -tr.c[i]; }
             const double xn = fma((double)x + 0.5, sx, -1.0), yn = fma((double)(a->row0 + y) + 0.5, sy, -1.0);
             const double e0 = cov_edge(&tr, 0, xn, yn), e1 = cov_edge(&tr, 1, xn, yn), e2 = cov_edge(&tr, 2, xn, yn);
-            const double s = (e0 + e1) + e2;
-#define GP_LERP(field, k) ((float)(fma(e2, (double)v[2].field[k], fma(e1, (double)v[1].field[k], e0 * (double)v[0].field[k])) / s))
+            const double inv_s = 1.0 / ((e0 + e1) + e2);  /* one division per pixel */
+#define GP_LERP(field, k) ((float)(fma(e2, (double)v[2].field[k], fma(e1, (double)v[1].field[k], e0 * (double)v[0].field[k])) * inv_s))
             const float u = GP_LERP(uv, 0), vv = GP_LERP(uv, 1);
             float pos[4], tbn[9];
             for (int k = 0; k < 4; k++) pos[k] = GP_LERP(pos, k);

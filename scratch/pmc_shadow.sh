@@ -1,0 +1,16 @@
+#!/bin/bash
+# Counter passes over the shadow / geometry / coverage kernels (scratch/shadow_bench.py).
+# usage: bash scratch/pmc_shadow.sh <out-subdir-of-gpurun_out>
+set -u
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/$1
+mkdir -p $OUT
+cd /tmp
+run() {
+  name=$1; shift
+  timeout -s KILL 200 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R/scratch/shadow_bench.py > $OUT/$name.log 2>&1 || { echo "pass $name failed"; tail -5 $OUT/$name.log; exit 1; }
+}
+run sq SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_BUSY_CYCLES && \
+run tcc TCC_ATOMIC_sum TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE
+echo passes done

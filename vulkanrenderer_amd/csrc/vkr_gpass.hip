@@ -106,13 +106,13 @@ __global__ __launch_bounds__(256) void gpass_visibility_kernel(const GpassParams
         }
     }
     const double sx = 2.0 / (double)p.width, sy = 2.0 / (double)p.frame_rows;
-    raster_boxes<true>(have, clip, clip, p.tri_base + (unsigned)t, bx0, by0, bx1, by1, [&](const STri &tr, const float (&)[3][4], unsigned id, int x, int y) {
+    raster_boxes<true, true>(have, clip, clip, p.tri_base + (unsigned)t, bx0, by0, bx1, by1, [&](const STri &tr, const float (&)[3][4], unsigned id, int x, int y) {
         const double xn = __builtin_fma((double)x + 0.5, sx, -1.0), yn = __builtin_fma((double)(p.row0 + y) + 0.5, sy, -1.0);
         const double e0 = s_edge(tr, 0, xn, yn), e1 = s_edge(tr, 1, xn, yn), e2 = s_edge(tr, 2, xn, yn);
         if (!(e0 >= 0.0 && e1 >= 0.0 && e2 >= 0.0 && (e0 + e1) + e2 > 0.0)) return;
         const double zs = __builtin_fma(e2, tr.z[2], __builtin_fma(e1, tr.z[1], e0 * tr.z[0]));
         if (!(zs >= 0.0 && zs <= tr.D)) return;
-        const float depth = (float)(zs / tr.D) + 0.0f;
+        const float depth = (float)(zs * tr.inv_D) + 0.0f;
         const unsigned long long key = ((unsigned long long)__builtin_bit_cast(unsigned int, depth) << 32) | (unsigned long long)id;
         atomicMin(p.vis + (size_t)y * p.width + x, key);
     });
@@ -171,8 +171,8 @@ __global__ __launch_bounds__(256) void gpass_resolve_kernel(const GpassParams p)
     const double sx = 2.0 / (double)p.width, sy = 2.0 / (double)p.frame_rows;
     const double xn = __builtin_fma((double)x + 0.5, sx, -1.0), yn = __builtin_fma((double)(p.row0 + y) + 0.5, sy, -1.0);
     const double e0 = s_edge(tr, 0, xn, yn), e1 = s_edge(tr, 1, xn, yn), e2 = s_edge(tr, 2, xn, yn);
-    const double s = (e0 + e1) + e2;
-    auto lerp = [&](float a0, float a1, float a2) { return (float)(__builtin_fma(e2, (double)a2, __builtin_fma(e1, (double)a1, e0 * (double)a0)) / s); };
+    const double inv_s = 1.0 / ((e0 + e1) + e2);  // one division per pixel
+    auto lerp = [&](float a0, float a1, float a2) { return (float)(__builtin_fma(e2, (double)a2, __builtin_fma(e1, (double)a1, e0 * (double)a0)) * inv_s); };
     const float u = lerp(v[0].uv[0], v[1].uv[0], v[2].uv[0]), vv = lerp(v[0].uv[1], v[1].uv[1], v[2].uv[1]);
     float pos[4], tbn[9];
 #pragma unroll

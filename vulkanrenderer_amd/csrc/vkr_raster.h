@@ -6,13 +6,14 @@
 // D > 0 is a back face under the reference's CCW-front convention, D < 0 a front face; the sample
 // is inside (and in front of the eye) when E0,E1,E2 and their sum have the sign of D, and its
 // depth passes the 0 <= z <= w clip when sum(Ei*zi) lies between 0 and D.  Attributes interpolate
-// perspective-correctly as sum(Ei*ai) / sum(Ei).
+// perspective-correctly as sum(Ei*ai) * (1 / sum(Ei)), and the depth is sum(Ei*zi) * (1 / D): one binary64
+// division per sample or per triangle, then multiplications.
 #pragma once
 #include "vkr_device.h"
 
 namespace vkr {
 
-struct STri { double a[3], b[3], c[3], z[3], D; };
+struct STri { double a[3], b[3], c[3], z[3], D, inv_D; };  // inv_D = 1 / D where the caller asks for it (raster_boxes<.., true>)
 
 VKR_DEV double s_edge(const STri &t, int i, double xn, double yn) { return __builtin_fma(t.a[i], xn, __builtin_fma(t.b[i], yn, t.c[i])); }
 
@@ -110,7 +111,7 @@ static constexpr int RASTER_BIG = 128;  // bounding boxes with more samples than
 // by the whole wave -- its owner's corners are broadcast, every lane redoes the (deterministic)
 // setup and takes every 64th sample -- so one screen-filling triangle does not leave 63 lanes idle.
 // Every lane of the wave must call this (no early returns before it).  FLIP: front faces were kept.
-template <bool FLIP, typename F>
+template <bool FLIP, bool INV_D, typename F>
 VKR_DEV void raster_boxes(bool have, const float (&clip)[3][4], const float (&attr)[3][4], unsigned tag,
                           int bx0, int by0, int bx1, int by1, F pixel)
 {
@@ -120,6 +121,7 @@ VKR_DEV void raster_boxes(bool have, const float (&clip)[3][4], const float (&at
         STri t;
         raster_setup(clip, t);
         if (FLIP) raster_flip(t);
+        if (INV_D) t.inv_D = 1.0 / t.D;
         for (int j = by0; j <= by1; j++)
             for (int i = bx0; i <= bx1; i++) pixel(t, attr, tag, i, j);
     }
@@ -139,6 +141,7 @@ VKR_DEV void raster_boxes(bool have, const float (&clip)[3][4], const float (&at
         STri t;
         raster_setup(c2, t);
         if (FLIP) raster_flip(t);
+        if (INV_D) t.inv_D = 1.0 / t.D;
         const long long total = (long long)w2 * h2;
         for (long long q = lane; q < total; q += 64) {
             const int jj = (int)(q / w2), ii = (int)(q - (long long)jj * w2);

@@ -6,7 +6,7 @@
 // A texel belongs to a triangle when its centre lies inside the projected back-facing triangle
 // and the depth there passes the 0 <= z <= w clip -- the homogeneous binary64 rule of the
 // light-volume coverage kernel -- and the world position the fragment shader receives is the
-// perspective-correct interpolation sum(Ei * Pi) / sum(Ei).  The stored value is the minimum over
+// perspective-correct interpolation sum(Ei * Pi) * (1 / sum(Ei)).  The stored value is the minimum over
 // all covering triangles (atomicMin on the bits of a non-negative float), so the result does not
 // depend on the order of triangles, lanes or launches.
 //
@@ -68,7 +68,7 @@ VKR_DEV void shadow_raster(bool valid, const float (&clip)[3][4], const float (&
         have = t.D > 0.0 && shadow_bbox(clip, res, bx0, by0, bx1, by1);  // front faces and degenerate triangles are culled
     }
     const double sc = 2.0 / (double)res;
-    raster_boxes<false>(have, clip, world, 0u, bx0, by0, bx1, by1, [&](const STri &t, const float (&wp)[3][4], unsigned, int i, int j) {
+    raster_boxes<false, !POINT>(have, clip, world, 0u, bx0, by0, bx1, by1, [&](const STri &t, const float (&wp)[3][4], unsigned, int i, int j) {
         const double xn = __builtin_fma((double)i + 0.5, sc, -1.0), yn = __builtin_fma((double)j + 0.5, sc, -1.0);
         const double e0 = s_edge(t, 0, xn, yn), e1 = s_edge(t, 1, xn, yn), e2 = s_edge(t, 2, xn, yn);
         const double s = (e0 + e1) + e2;
@@ -78,13 +78,14 @@ VKR_DEV void shadow_raster(bool valid, const float (&clip)[3][4], const float (&
         float depth;
         if (POINT) {  // point_shadow.frag:11-16 on the interpolated world position
             float pw[3];
+            const double inv_s = 1.0 / s;
 #pragma unroll
             for (int k = 0; k < 3; k++)
-                pw[k] = (float)(__builtin_fma(e2, (double)wp[2][k], __builtin_fma(e1, (double)wp[1][k], e0 * (double)wp[0][k])) / s);
+                pw[k] = (float)(__builtin_fma(e2, (double)wp[2][k], __builtin_fma(e1, (double)wp[1][k], e0 * (double)wp[0][k])) * inv_s);
             const f3 d = mk3(pw[0] - light_pos[0], pw[1] - light_pos[1], pw[2] - light_pos[2]);
             depth = sqrt_rn(dot3(d, d)) * inv_far;
         } else {
-            depth = (float)(zs / t.D) + 0.0f;  // z / w of the fixed-function pipeline (-0 becomes +0)
+            depth = (float)(zs * t.inv_D) + 0.0f;  // z / w of the fixed-function pipeline as z * (1/w) (-0 becomes +0)
         }
         if (depth < 1.0f)  // CompareOp.Less against the cleared 1.0 and every earlier write; depth >= 0 here
             atomicMin((unsigned int *)(img + depth_texel_index(res, i, j, tiled)), __builtin_bit_cast(unsigned int, depth));
