@@ -15,8 +15,11 @@ __global__ __launch_bounds__(256) void rate_kernel(float *out, float a, float b)
     float2_t p[8];
     int n[8];
     unsigned long long m[8] = {};
+    double dd[8];
+    int sg[8] = {};
+    const double da = a, db = b;
 #pragma unroll
-    for (int k = 0; k < 8; k++) { x[k] = (float)(threadIdx.x + k); p[k] = float2_t{x[k], x[k] + 1.0f}; n[k] = threadIdx.x + k; }
+    for (int k = 0; k < 8; k++) { dd[k] = (double)(threadIdx.x + k) + 0.5; x[k] = (float)(threadIdx.x + k); p[k] = float2_t{x[k], x[k] + 1.0f}; n[k] = threadIdx.x + k; }
     const float2_t pa = {a, a}, pb = {b, b};
     for (int it = 0; it < ITER; it++) {
 #pragma unroll
@@ -44,12 +47,20 @@ __global__ __launch_bounds__(256) void rate_kernel(float *out, float a, float b)
             if (MODE == 21) asm volatile("v_max3_f32 %0, |%0|, |%1|, |%2|" : "+v"(x[k]) : "v"(a), "v"(b));
             if (MODE == 22) asm volatile("v_cmp_gt_f32 %0, %1, %2" : "=s"(m[k]) : "v"(x[k]), "v"(a));
             if (MODE == 23) asm volatile("v_lshl_add_u32 %0, %0, 5, %1" : "+v"(n[k]) : "v"(n[0]));
+            if (MODE == 24) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(dd[k]) : "v"(da), "v"(db));
+            if (MODE == 25) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(dd[k]) : "v"(da));
+            if (MODE == 26) asm volatile("v_add_f64 %0, %0, %1" : "+v"(dd[k]) : "v"(da));
+            if (MODE == 27) asm volatile("v_rcp_f64 %0, %0" : "+v"(dd[k]));
+            if (MODE == 28) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(dd[k]) : "v"(x[k]));
+            if (MODE == 29) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(x[k]) : "v"(dd[k]));
+            if (MODE == 30) asm volatile("v_readlane_b32 %0, %1, 5" : "=s"(sg[k]) : "v"(x[k]));
+            if (MODE == 31) asm volatile("v_cmp_ge_f64 %0, %1, %2" : "=s"(m[k]) : "v"(dd[k]), "v"(da));
             if (MODE == 11) asm volatile("v_cvt_f16_f32 %0, %0\n\tv_cvt_f32_f16 %0, %0" : "+v"(x[k]));
         }
     }
     float s = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 8; k++) s += x[k] + p[k].x + p[k].y + (float)n[k] + (float)m[k];
+    for (int k = 0; k < 8; k++) s += x[k] + p[k].x + p[k].y + (float)n[k] + (float)m[k] + (float)dd[k] + (float)sg[k];
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
@@ -101,5 +112,13 @@ int main()
     run<21>("v_max3_f32 |.|", out, 1);
     run<22>("v_cmp_gt_f32 -> sgpr", out, 1);
     run<23>("v_lshl_add_u32", out, 1);
+    run<24>("v_fma_f64", out, 2);
+    run<25>("v_mul_f64", out, 1);
+    run<26>("v_add_f64", out, 1);
+    run<27>("v_rcp_f64", out, 1);
+    run<28>("v_cvt_f64_f32", out, 1);
+    run<29>("v_cvt_f32_f64", out, 1);
+    run<30>("v_readlane_b32", out, 1);
+    run<31>("v_cmp_ge_f64 -> sgpr", out, 1);
     return 0;
 }

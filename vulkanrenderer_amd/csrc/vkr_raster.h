@@ -142,10 +142,15 @@ VKR_DEV void raster_boxes(bool have, const float (&clip)[3][4], const float (&at
         raster_setup(c2, t);
         if (FLIP) raster_flip(t);
         if (INV_D) t.inv_D = 1.0 / t.D;
-        const long long total = (long long)w2 * h2;
-        for (long long q = lane; q < total; q += 64) {
-            const int jj = (int)(q / w2), ii = (int)(q - (long long)jj * w2);
-            pixel(t, a2, tag2, x0 + ii, y0 + jj);
+        // sample q = lane, lane + 64, ... of the box in row order; (ii, jj) advance by 64 samples without a
+        // division per step (boxes hold fewer than 2^31 samples: faces and frames are at most 32768 wide)
+        const unsigned uw = (unsigned)w2, total = uw * (unsigned)h2;
+        const unsigned step_rows = 64u / uw, step_cols = 64u - step_rows * uw;
+        unsigned jj = (unsigned)lane / uw, ii = (unsigned)lane - jj * uw;
+        for (unsigned q = (unsigned)lane; q < total; q += 64u) {
+            pixel(t, a2, tag2, x0 + (int)ii, y0 + (int)jj);
+            ii += step_cols; jj += step_rows;
+            if (ii >= uw) { ii -= uw; jj++; }
         }
     }
 }

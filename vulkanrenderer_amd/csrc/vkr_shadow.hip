@@ -14,6 +14,7 @@
 // turn and walks the texels of its bounding box.  Output texels are addressed row-major or as
 // 8x4-texel tiles, the layout the shading kernel gathers from fastest.
 #include "vkr_device.h"
+#include "vkr_fastmath.h"
 #include "vkr_host.h"
 #include "vkr_raster.h"
 
@@ -83,7 +84,7 @@ VKR_DEV void shadow_raster(bool valid, const float (&clip)[3][4], const float (&
             for (int k = 0; k < 3; k++)
                 pw[k] = (float)(__builtin_fma(e2, (double)wp[2][k], __builtin_fma(e1, (double)wp[1][k], e0 * (double)wp[0][k])) * inv_s);
             const f3 d = mk3(pw[0] - light_pos[0], pw[1] - light_pos[1], pw[2] - light_pos[2]);
-            depth = sqrt_rn(dot3(d, d)) * inv_far;
+            depth = sqrt_rn_checked(dot3(d, d)) * inv_far;
         } else {
             depth = (float)(zs * t.inv_D) + 0.0f;  // z / w of the fixed-function pipeline as z * (1/w) (-0 becomes +0)
         }
