@@ -69,7 +69,7 @@ class HipBackend:
     def frame_from_draws(self, frame, draws, shadow_res, dir_res, frame_rows, row0, env=None):
         """This strip's G-buffer and the (replicated) shadow maps rendered from draw calls: `frame` supplies the
         scene constants, lights and IBL images; `draws` are the dicts passes.gbuffer takes.  Each rank renders
-        all shadow maps itself: re-rendering 64 cubes (2.3 ms) is cheaper than moving 1.5 GB between GPUs.
+        all shadow maps itself: re-rendering 64 cubes (1.8 ms) is cheaper than moving 1.5 GB between GPUs.
         `env` = (environment cube tensor, VKR_ENV_LAYOUT_*): the skybox is drawn behind the strip's geometry."""
         import dataclasses
         P = self.P
