@@ -29,11 +29,12 @@ class OracleBackend:
     def _bits(t):
         return t.numpy().view(np.uint16)
 
-    def shade(self, frame, color, thr):
+    def shade(self, frame, color, thr, y0=0, y1=None):
         from tests import oracle
-        c, t = oracle.shade(frame, getattr(frame, "background_image", None), coverage=getattr(frame, "coverage_masks", None))
-        self._bits(color)[...] = c
-        self._bits(thr)[...] = t
+        y1 = frame.height if y1 is None else y1
+        c, t = oracle.shade(frame, getattr(frame, "background_image", None), rows=(y0, y1), coverage=getattr(frame, "coverage_masks", None))
+        self._bits(color)[y0:y1] = c[y0:y1]
+        self._bits(thr)[y0:y1] = t[y0:y1]
 
     def frame_from_draws(self, frame, draws, shadow_res, dir_res, frame_rows, row0, env=None):
         import dataclasses
@@ -53,9 +54,10 @@ class OracleBackend:
         frame.coverage_masks = oracle.light_coverage(frame.scene, frame.lights, verts, tris, frame.width, frame.height, frame_rows, row0)
         return frame
 
-    def bloom_h(self, thr, bloom1, rows):
+    def bloom_h(self, thr, bloom1, rows, y0=0, y1=None):
         from tests import oracle
-        self._bits(bloom1)[HALO:HALO + rows] = oracle.bloom_blur(self._bits(thr), True, oracle.WRAP_REPEAT)
+        y1 = rows if y1 is None else y1
+        self._bits(bloom1)[HALO + y0:HALO + y1] = oracle.bloom_blur(np.ascontiguousarray(self._bits(thr)[y0:y1]), True, oracle.WRAP_REPEAT)
 
     def bloomv_post(self, bloom1, hdr, out, lo, hi, row0=0):
         from tests import oracle

@@ -63,8 +63,18 @@ class HipBackend:
     def empty(self, shape, dtype):
         return torch.empty(shape, dtype=dtype, device=self.device)
 
-    def shade(self, frame, color, thr):
-        self.P.shade(frame, color, thr)
+    def shade(self, frame, color, thr, y0=0, y1=None):
+        """Rows [y0, y1) of the strip (all of it by default); y0 is a multiple of 8 when masks are attached."""
+        if y0 == 0 and (y1 is None or y1 == frame.rows):
+            self.P.shade(frame, color, thr)
+            return
+        cut = lambda t: None if t is None else t[y0:y1]
+        tiles_x = (frame.width + 7) // 8
+        part = dataclasses.replace(frame, rows=y1 - y0, albedo=cut(frame.albedo), normal=cut(frame.normal), arm=cut(frame.arm),
+                                   position=cut(frame.position), background=cut(frame.background),
+                                   coverage=None if frame.coverage is None else frame.coverage[:, y0 // 8:(y1 + 7) // 8].contiguous())
+        assert frame.coverage is None or (y0 % 8 == 0 and part.coverage.shape[-1] == tiles_x)
+        self.P.shade(part, color[y0:y1], thr[y0:y1])
 
     def frame_from_draws(self, frame, draws, shadow_res, dir_res, frame_rows, row0, env=None):
         """This strip's G-buffer and the (replicated) shadow maps rendered from draw calls: `frame` supplies the
@@ -87,9 +97,10 @@ class HipBackend:
         verts, tris = volume_mesh
         return dataclasses.replace(frame, coverage=self.P.light_coverage(frame, verts, tris, frame_rows, row0))
 
-    def bloom_h(self, thr, bloom1, rows):
-        # writes rows [HALO, HALO + rows) of the halo-padded pass-1 image
-        self.P.bloom_blur(thr, bloom1[HALO:HALO + rows], True, _lib.WRAP_REPEAT, rows=rows)
+    def bloom_h(self, thr, bloom1, rows, y0=0, y1=None):
+        # writes rows [HALO + y0, HALO + y1) of the halo-padded pass-1 image (the whole strip by default)
+        y1 = rows if y1 is None else y1
+        self.P.bloom_blur(thr[y0:y1], bloom1[HALO + y0:HALO + y1], True, _lib.WRAP_REPEAT, rows=y1 - y0)
 
     def bloomv_post(self, bloom1, hdr, out, lo, hi, row0=0):
         # output row k of `hdr`/`out` is strip row row0 + k, centred on row HALO + row0 + k of bloom1
@@ -145,8 +156,9 @@ class StripRenderer:
         return self.render(self.backend.frame_from_draws(frame, draws, shadow_res, dir_res, p.total_rows, p.row0, env), volume_mesh)
 
     def render(self, frame, volume_mesh=None) -> torch.Tensor:
-        """composition -> bloom 1 -> halo exchange overlapped with the interior rows of bloom 2 +
-        post-process -> the rows next to a neighbour; returns the RGBA8 strip.  With `volume_mesh`
+        """composition and bloom 1 of the rows next to a neighbour -> halo exchange, overlapped with
+        composition and bloom 1 of all other rows and the interior rows of bloom 2 + post-process ->
+        the rows next to a neighbour; returns the RGBA8 strip.  With `volume_mesh`
         each light's draw is limited to the pixels its volume covers; the strip's place in the
         frame (plan.row0 of plan.total_rows) enters the projection, nothing is exchanged for it."""
         p, r = self.plan, self.plan.rows
@@ -157,15 +169,24 @@ class StripRenderer:
             self._slot_free[self._slot] = None
         if volume_mesh is not None:
             frame = be.with_coverage(frame, volume_mesh, p.total_rows, p.row0)
-        be.shade(frame, self.color, self.threshold)
-        be.bloom_h(self.threshold, self.bloom1, r)
         # frame edges clamp (CLAMP_TO_EDGE); interior strip edges read the neighbours' rows
         lo = HALO if p.is_top else 0
         hi = HALO + r - 1 if p.is_bottom else r + 2 * HALO - 1
         # rows [top, bottom) reach no halo row: they run while the halo rows are in flight
         top = 0 if p.is_top else HALO
         bottom = r if p.is_bottom else r - HALO
+        # The rows a neighbour needs are shaded and blurred first (bands of whole 8-row tiles), so that the
+        # halo exchange is in flight during the shading of everything else, the long part of a frame.
+        a = 0 if p.is_top else min(8, r)
+        b = r if p.is_bottom else max(((r - HALO) // 8) * 8, a)
+        for y0, y1 in ((0, a), (b, r)):
+            if y1 > y0:
+                be.shade(frame, self.color, self.threshold, y0, y1)
+                be.bloom_h(self.threshold, self.bloom1, r, y0, y1)
         pending = self.start_halo_exchange()
+        if b > a:
+            be.shade(frame, self.color, self.threshold, a, b)
+            be.bloom_h(self.threshold, self.bloom1, r, a, b)
         if bottom > top:
             be.bloomv_post(self.bloom1, self.color[top:bottom], self.ldr[top:bottom], lo, hi, row0=top)
         for req in pending:
