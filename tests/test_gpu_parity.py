@@ -913,3 +913,14 @@ def test_shade_lights_on_cube_edges_corners_and_surfaces(gpu, oracle):
         P.shade(d, color, thr)
         assert_bits_equal(P.f16_bits(color), want_c, f"colour (tiled cubes: {tiled})")
         assert_bits_equal(P.f16_bits(thr), want_t, f"threshold (tiled cubes: {tiled})")
+
+
+def test_graft_entry_smoke(gpu):
+    """The round-end smoke check itself (one frame through layer 2 + a small IBL precompute against the oracle)."""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    importlib.import_module("__graft_entry__").smoke()
