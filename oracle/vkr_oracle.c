@@ -159,6 +159,16 @@ static inline int wrap_i(int i, int n, int mode)
     return i < 0 ? 0 : (i >= n ? n - 1 : i);
 }
 
+/* float -> int as the GPU's conversion instruction defines it (C leaves NaN and out-of-range values
+ * undefined): NaN gives 0, everything else saturates.  Only non-finite inputs ever get here with such values. */
+static inline int f2i_sat(float x)
+{
+    if (x != x) return 0;
+    if (x >= 2147483648.0f) return 2147483647;
+    if (x <= -2147483648.0f) return -2147483647 - 1;
+    return (int)x;
+}
+
 /* shadowSampler (VulkanHelper.cs:189-220): NEAREST, CLAMP_TO_BORDER, border = opaque white (1.0) */
 static inline float tex2d_depth_nearest_border(const float *img, int res, float s, float t)
 {
@@ -204,7 +214,7 @@ static inline float texcube_depth_nearest(const float *cube, int res, v3 r)
 {
     int face; float s, t;
     cube_st(r, &face, &s, &t);
-    int i = (int)floorf(s * (float)res), j = (int)floorf(t * (float)res);
+    int i = f2i_sat(floorf(s * (float)res)), j = f2i_sat(floorf(t * (float)res));
     i = i < 0 ? 0 : (i >= res ? res - 1 : i);
     j = j < 0 ? 0 : (j >= res ? res - 1 : j);
     return cube[((size_t)face * res + j) * res + i];
@@ -257,7 +267,7 @@ static inline v3 texcube_rgb_linear(const uint16_t *cube, int n, v3 r)
     float x = s * (float)n - 0.5f, y = t * (float)n - 0.5f;
     float fx = floorf(x), fy = floorf(y);
     float al = x - fx, be = y - fy;
-    int i0 = (int)fx, j0 = (int)fy;
+    int i0 = f2i_sat(fx), j0 = f2i_sat(fy);
     float w[4] = {(1.0f - al) * (1.0f - be), al * (1.0f - be), (1.0f - al) * be, al * be};
     float tx[4][3];
     int ok[4], nok = 0;

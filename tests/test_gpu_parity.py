@@ -924,3 +924,33 @@ def test_graft_entry_smoke(gpu):
     if root not in sys.path:
         sys.path.insert(0, root)
     importlib.import_module("__graft_entry__").smoke()
+
+
+def test_shade_with_non_finite_and_huge_inputs(gpu, oracle):
+    """Infinite and NaN positions in the G-buffer and lights 1e30 .. 3e38 away: the kernel stays inside its
+    images (the unclamped one-face path is only taken for tame coordinates) and every pixel whose own inputs
+    are finite still equals the oracle bit for bit."""
+    torch, P = _torch(), _passes()
+    w, h, nl, cube = 96, 64, 4, 32
+    f = synth.make_frame(98, w, h, nl, cube, 64, irr_res=8, pref_res=16, lut_res=32)
+    pos = f.position.copy()
+    pos[10:14, 20:30, 0] = 0x7C00          # +inf
+    pos[30:33, 40:48, 1] = 0xFC00          # -inf
+    pos[50:52, 60:70, 2] = 0x7E00          # NaN
+    pos[5, 5, :3] = 0x7BFF                 # largest finite binary16
+    f.position = pos
+    lights = f.lights.copy()
+    lights["position"][0] = (1e30, -2e30, 3e30)
+    lights["position"][1] = (3e38, 3e38, -3e38)
+    f.lights = lights
+    want_c, want_t = oracle.shade(f)
+    finite = np.isfinite(oracle.f16_to_f32(pos)[..., :3]).all(-1)
+    for tiled in (True, False):
+        d = P.DeviceFrame.upload(f, gpu, tiled=tiled)
+        color = torch.empty((h, w, 4), dtype=torch.float16, device=gpu)
+        thr = torch.empty_like(color)
+        P.shade(d, color, thr)
+        torch.cuda.synchronize()
+        got_c, got_t = P.f16_bits(color), P.f16_bits(thr)
+        assert_bits_equal(got_c[finite], want_c[finite], f"colour of the finite pixels (tiled cubes: {tiled})")
+        assert_bits_equal(got_t[finite], want_t[finite], f"threshold of the finite pixels (tiled cubes: {tiled})")

@@ -342,6 +342,9 @@ VKR_DEV int wave_common_face(float fx, float fy, float fz, float r)
     else if (all2(zhi < ys, ys >= xhi)) { axis = 2; major = fy; }    // never z major, always y over x
     else if (all2(zhi < xs, yhi < xs)) { axis = 0; major = fx; }     // never z major, never y over x
     else return -1;
+    // beyond 2^100 the fast reciprocal leaves its exact domain (and infinity passes the comparisons above):
+    // such waves take the clamped path, which stays inside the cube whatever the coordinates are
+    if (__builtin_amdgcn_ballot_w64(__builtin_fabsf(major) < 0x1p100f) != active) return -1;
     const unsigned long long neg = __builtin_amdgcn_ballot_w64(major < 0.0f);
     return neg == 0ull ? axis : (neg == active ? axis + 1 : -1);
 }
