@@ -369,9 +369,14 @@ VKR_DEV void tile_of_block(unsigned b, int tiles_x, int tiles_y, int &tx, int &t
     tx = (int)(cb * CB + r % cbw);
 }
 
-// Five waves per SIMD (96 VGPRs, none spilled).  Measured at 4K / 64 lights with this loop: 5 waves 3.74 ms,
-// 6 waves (80 VGPRs, one value reloaded from scratch memory per light) 3.77 ms; an earlier, longer loop
+// Five waves per SIMD (96 VGPRs, none spilled).  Measured at 4K / 64 lights with this loop: 5 waves 3.58 ms,
+// 6 waves (80 VGPRs, values reloaded from scratch memory inside the loop) 3.72 ms; an earlier, longer loop
 // measured 4 waves 5.5 ms, 5 waves 4.6, 6 waves 4.5, 7 waves (spills inside the loop) 4.6.
+// The loop is bound by VALU issue, and on this chip v_add/mul/fma_f32 issue in about 3 clocks per wave while
+// every integer, compare, select, convert and min/max instruction takes a little over 4 and a reciprocal or
+// root 8: the code below prefers the former (clamped fmas for comparisons, signed reciprocals instead of
+// selects, votes on scalar masks).  The whole kernel is kept under about 30 KB of code: a 36 KB variant
+// ran 25 % slower for instruction-cache misses alone.
 // MASKED: each light's draw touches only the pixels its light volume covers (one 64-bit mask per
 // light and tile, bit = lane); a light that covers none of the wave's pixels is skipped whole.
 template <bool TILED, bool POW2, bool MASKED>
