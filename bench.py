@@ -61,14 +61,14 @@ def time_shadow_retile(f, device, reps: int = 5) -> dict:
     """Row-major -> 8x4-tile re-layout of all point-shadow cubes: what a caller pays per frame if its
     shadow pass hands over row-major depth maps (a native shadow pass would write tiles directly)."""
     import torch
-    from vulkanrenderer_amd import passes as P
+    from vulkanrenderer_amd import _lib, passes as P
     lin = torch.from_numpy(f.cube_shadow).to(device)
-    P.tile_depth_cubes(lin)
+    P.tile_depth_cubes(lin, _lib.CUBE_LAYOUT_TILED_8X4_X25)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        P.tile_depth_cubes(lin)
+        P.tile_depth_cubes(lin, _lib.CUBE_LAYOUT_TILED_8X4_X25)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
@@ -343,7 +343,7 @@ def main() -> None:
         "config": {"workload": f"{WIDTH}x{HEIGHT} strip per GPU ({WIDTH}x{HEIGHT * world} frame), {args.lights} point lights with "
                                f"{args.cube_res}^2 cube shadow maps + {args.dir_res}^2 directional PCF shadow; composition + bloom x2 + ACES/gamma",
                    "parallelism": f"strips{world}",
-                   "storage": "RGBA16F G-buffer and targets, RGBA8 output, D32F shadow cubes in 8x4-texel tiles"},
+                   "storage": "RGBA16F G-buffer and targets, RGBA8 output, D32F shadow cubes in 8x4-texel tiles holding 25 x depth (the product light.frag forms per tap)"},
         "roofline": {"bound": "valu", "kernel": "shade_kernel", "achieved": round(shade_tflops, 3), "peak": PEAK_FP32_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(shade_tflops / PEAK_FP32_TFLOPS, 4), "traffic": traffic.get("shade_kernel"),
                      "algorithmic": f"({OPS_PER_PIXEL} + {OPS_PER_PIXEL_LIGHT} x {args.lights}) FP32 ops x {shaded_px} shaded pixels per launch "

@@ -75,6 +75,10 @@ typedef struct VkrLightInfo {
 #define VKR_CUBE_LAYOUT_LINEAR 0    /* [light][face][row][column], tight */
 #define VKR_CUBE_LAYOUT_TILED_8X4 1 /* each face as row-major 8x4-texel tiles of 128 bytes; face size % 8 == 0;
                                        made from the linear layout by vkr_tile_depth_cubes() */
+#define VKR_CUBE_LAYOUT_TILED_8X4_X25 2 /* the same tiles holding RN(25 * depth), the product light.frag:133 forms for
+                                           every tap (25 = the shadow passes' far plane, VulkanRenderer.cs:331): the
+                                           shading kernel then compares without multiplying; made by
+                                           vkr_relayout_depth_cubes() or written directly by vkr_point_shadow_maps() */
 
 /* Memory layout of the RGBA16F environment cube read by the irradiance and prefilter passes. */
 #define VKR_ENV_LAYOUT_LINEAR 0    /* [face][row][column], tight */
@@ -215,6 +219,8 @@ VKR_EXPORT int32_t vkr_skybox(const void *env, int32_t env_n, int32_t env_layout
  * VKR_CUBE_LAYOUT_TILED_8X4 (res % 8 == 0; src and dst must not overlap).  No counterpart in the
  * reference, whose depth images are written tiled by the rasteriser. */
 VKR_EXPORT int32_t vkr_tile_depth_cubes(const float *linear, float *tiled, int32_t n_faces, int32_t res, void *stream);
+/* The same for either tiled layout (VKR_CUBE_LAYOUT_TILED_8X4 or VKR_CUBE_LAYOUT_TILED_8X4_X25). */
+VKR_EXPORT int32_t vkr_relayout_depth_cubes(const float *linear, float *out, int32_t n_faces, int32_t res, int32_t layout, void *stream);
 
 /* Replaces one bloom_blur.frag draw (VulkanRenderer.cs:504-540).  Writes `rows` output rows;
  * output row r is centred on source row r + src_row_offset.  Taps along the blur axis wrap

@@ -333,17 +333,21 @@ def test_cpp_host_program_matches_oracle(gpu, oracle, tmp_path):
 
 @pytest.mark.parametrize("seed,w,h,nl,cube,dres", FRAMES)
 def test_shade_bit_exact_with_row_major_cubes(gpu, oracle, seed, w, h, nl, cube, dres):
-    """The same frames with the point-shadow cubes left row-major (test_shade_bit_exact uses 8x4 tiles)."""
+    """The same frames with the point-shadow cubes left row-major, and as 8x4 tiles of the plain depth
+    (test_shade_bit_exact uses the default: tiles of 25 * depth where the face size allows)."""
     torch, P = _torch(), _passes()
     f = synth.make_frame(seed, w, h, nl, cube, dres, irr_res=8, pref_res=16, lut_res=32)
     want_c, want_t = oracle.shade(f)
-    d = P.DeviceFrame.upload(f, gpu, tiled=False)
-    assert d.cube_layout == _lib.CUBE_LAYOUT_LINEAR
-    color = torch.empty((h, w, 4), dtype=torch.float16, device=gpu)
-    thr = torch.empty_like(color)
-    P.shade(d, color, thr)
-    assert_bits_equal(P.f16_bits(color), want_c, "composition colour")
-    assert_bits_equal(P.f16_bits(thr), want_t, "thresholded colour")
+    for tiled in (False, True):
+        if tiled and (cube % 8 != 0 or nl == 0):
+            continue
+        d = P.DeviceFrame.upload(f, gpu, tiled=tiled)
+        assert d.cube_layout == (_lib.CUBE_LAYOUT_TILED_8X4 if tiled else _lib.CUBE_LAYOUT_LINEAR)
+        color = torch.empty((h, w, 4), dtype=torch.float16, device=gpu)
+        thr = torch.empty_like(color)
+        P.shade(d, color, thr)
+        assert_bits_equal(P.f16_bits(color), want_c, f"composition colour (tiled: {tiled})")
+        assert_bits_equal(P.f16_bits(thr), want_t, f"thresholded colour (tiled: {tiled})")
 
 
 def test_tiled_cube_layout(gpu, oracle):
@@ -359,6 +363,10 @@ def test_tiled_cube_layout(gpu, oracle):
     want = np.empty_like(got)
     want[:, index.ravel()] = src.reshape(12, -1)
     assert np.array_equal(got, want)
+    got25 = P.tile_depth_cubes(lin, _lib.CUBE_LAYOUT_TILED_8X4_X25).cpu().numpy().reshape(12, -1)
+    assert np.array_equal(got25, want * np.float32(25.0))          # the product light.frag forms per tap, rounded once
+    with pytest.raises(_lib.VkrError):
+        P.tile_depth_cubes(lin, _lib.CUBE_LAYOUT_LINEAR)
 
     f = synth.make_frame(15, 72, 40, 2, 12, 64, irr_res=8, pref_res=16, lut_res=32)  # 12^2 faces
     d = P.DeviceFrame.upload(f, gpu)
@@ -529,10 +537,10 @@ def _device_draws(draws, gpu):
              torch.from_numpy(np.ascontiguousarray(t).astype(np.int32)).to(gpu), m) for v, t, m in draws]
 
 
-@pytest.mark.parametrize("res,tiled", [(64, False), (64, True), (90, False)])
+@pytest.mark.parametrize("res,tiled", [(64, False), (64, True), (64, None), (90, False)])
 def test_point_shadow_maps_bit_exact(gpu, oracle, res, tiled):
     """vkr_point_shadow_maps against the oracle: the closed height-field slab plus a moved, scaled sphere,
-    lights above, beside and inside the geometry; row-major and tiled output."""
+    lights above, beside and inside the geometry; row-major output, tiles, and tiles of 25 * depth (None)."""
     torch, P = _torch(), _passes()
     slab = synth.make_scene_mesh(24)
     ball = synth.make_sphere_mesh(16, 8)
@@ -547,10 +555,13 @@ def test_point_shadow_maps_bit_exact(gpu, oracle, res, tiled):
     dev_lights = torch.from_numpy(np.frombuffer(lights.tobytes(), dtype=np.uint8).copy()).to(gpu)
     got, layout = P.point_shadow_maps(_device_draws(draws, gpu), dev_lights, len(lights), res, tiled=tiled)
     got = got.cpu().numpy()
-    if tiled:
+    if tiled is not False:
         j, i = np.meshgrid(np.arange(res), np.arange(res), indexing="ij")
         index = ((j >> 2) * (res >> 3) + (i >> 3)) * 32 + (j & 3) * 8 + (i & 7)
         got = got.reshape(len(lights), 6, -1)[:, :, index.ravel()].reshape(want.shape)
+    if tiled is None:
+        assert layout == _lib.CUBE_LAYOUT_TILED_8X4_X25
+        want = want * np.float32(25.0)
     bad = got.view(np.uint32) != want.view(np.uint32)
     assert not bad.any(), f"{bad.sum()} of {bad.size} texels differ, first at {np.argwhere(bad)[0]}"
 
@@ -583,7 +594,7 @@ def test_generated_shadow_maps_feed_the_shading_pass(gpu, oracle):
     d = P.DeviceFrame.upload(f, gpu)
     ddraws = _device_draws(draws, gpu)
     d.cube_shadow, d.cube_layout = P.point_shadow_maps(ddraws, d.lights, nl, 64)
-    assert d.cube_layout == _lib.CUBE_LAYOUT_TILED_8X4
+    assert d.cube_layout == _lib.CUBE_LAYOUT_TILED_8X4_X25
     d.dir_shadow = P.dir_shadow_map(ddraws, f.scene["light_space_matrix"], 128, gpu)
     color = torch.empty((h, w, 4), dtype=torch.float16, device=gpu)
     thr = torch.empty_like(color)

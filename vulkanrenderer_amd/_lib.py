@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("VKR_HIP_LIB") or os.path.join(_HERE, "libvkr_hip.so")
 VKR_OK = 0
 VKR_ERR_INVALID, VKR_ERR_HIP, VKR_ERR_UNSUPPORTED, VKR_ERR_ORDER, VKR_ERR_NO_DEVICE = -1, -2, -3, -4, -5
 COVERAGE_FULLSCREEN, COVERAGE_MESH = 0, 1
-CUBE_LAYOUT_LINEAR, CUBE_LAYOUT_TILED_8X4 = 0, 1
+CUBE_LAYOUT_LINEAR, CUBE_LAYOUT_TILED_8X4, CUBE_LAYOUT_TILED_8X4_X25 = 0, 1, 2
 ENV_LAYOUT_LINEAR, ENV_LAYOUT_TILED_4X4 = 0, 1
 WRAP_REPEAT, WRAP_CLAMP = 0, 1
 SRC_RGBA8_SRGB, SRC_RGBA16F = 0, 1
@@ -134,6 +134,7 @@ PROTOTYPES = {
     "vkr_device_count": [],
     "vkr_shade": [C.POINTER(ShadeArgs), _vp],
     "vkr_tile_depth_cubes": [_vp, _vp, C.c_int32, C.c_int32, _vp],
+    "vkr_relayout_depth_cubes": [_vp, _vp, _i32, _i32, _i32, _vp],
     "vkr_light_coverage": [C.POINTER(CoverageArgs), _vp],
     "vkr_point_shadow_maps": [C.POINTER(PointShadowArgs), _vp],
     "vkr_gbuffer": [C.POINTER(GpassArgs), _vp],

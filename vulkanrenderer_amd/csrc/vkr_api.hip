@@ -60,7 +60,7 @@ struct vkr_ctx {
     std::vector<int> draw_mesh, draw_material;  // per draw call; material -1: the draw only casts shadows
     void *gp_workspace = nullptr;        // visibility keys + draw records of the geometry pass
     int64_t gp_workspace_bytes = 0;
-    bool cubes_tiled = false;       // point shadow cubes are stored VKR_CUBE_LAYOUT_TILED_8X4
+    bool cubes_tiled = false;       // point shadow cubes are stored VKR_CUBE_LAYOUT_TILED_8X4_X25
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timing_valid = false;
 };
@@ -146,7 +146,7 @@ static int32_t fill_shade_args(vkr_ctx *c, Frame &f, VkrShadeArgs &a)
     a.lights = f.lights; a.n_lights = f.n_lights; a.coverage_mode = f.coverage;
     a.dir_shadow = f.dir_shadow; a.dir_res = c->cfg.dir_shadow_res;
     a.cube_shadow = f.cube_shadow; a.cube_res = c->cfg.point_shadow_res;
-    a.cube_layout = c->cubes_tiled ? VKR_CUBE_LAYOUT_TILED_8X4 : VKR_CUBE_LAYOUT_LINEAR;
+    a.cube_layout = c->cubes_tiled ? VKR_CUBE_LAYOUT_TILED_8X4_X25 : VKR_CUBE_LAYOUT_LINEAR;
     a.irradiance = c->irradiance; a.irr_res = c->cfg.irradiance_res;
     a.prefilter = c->prefilter[0]; a.pref_res = c->cfg.prefilter_res;
     a.brdf_lut = c->brdf_lut; a.lut_res = c->cfg.brdf_lut_res;
@@ -198,7 +198,7 @@ static int32_t run_shadow_passes(vkr_ctx *c, Frame &f)
     ps.draws = c->draw_calls.data(); ps.n_draws = (int32_t)c->draw_calls.size();
     ps.lights = f.lights; ps.n_lights = f.n_lights;
     ps.res = c->cfg.point_shadow_res; ps.far_plane = 25.0f;  // VulkanRenderer.cs:331
-    ps.layout = c->cubes_tiled ? VKR_CUBE_LAYOUT_TILED_8X4 : VKR_CUBE_LAYOUT_LINEAR;
+    ps.layout = c->cubes_tiled ? VKR_CUBE_LAYOUT_TILED_8X4_X25 : VKR_CUBE_LAYOUT_LINEAR;
     ps.out = f.cube_shadow;
     int32_t rc = vkr_point_shadow_maps(&ps, c->stream);
     if (rc != VKR_OK) return rc;
@@ -533,7 +533,7 @@ extern "C" int32_t vkr_upload_point_shadow(vkr_ctx *c, int32_t light, const floa
     if (!c->cubes_tiled) return upload(c, dst, depth_cube, per * 4);
     // host rows -> staging -> 8x4-texel tiles (what the shade kernel's gathers are laid out for)
     VKR_HIP_CHECK(hipMemcpyAsync(c->cube_staging, depth_cube, per * 4, hipMemcpyHostToDevice, c->stream));
-    int32_t rc = vkr_tile_depth_cubes(c->cube_staging, dst, 6, c->cfg.point_shadow_res, c->stream);
+    int32_t rc = vkr_relayout_depth_cubes(c->cube_staging, dst, 6, c->cfg.point_shadow_res, VKR_CUBE_LAYOUT_TILED_8X4_X25, c->stream);
     if (rc != VKR_OK) return rc;
     VKR_HIP_CHECK(hipStreamSynchronize(c->stream));
     return VKR_OK;

@@ -175,7 +175,7 @@ VKR_DEV float step_closer(float closest, float cur_s)
 // Number of the 20 taps whose stored depth is closer than `cur` when every tap of every lane of
 // the wave lies on one cube face of axis AXIS (`face_base` points at it).  The index triple of a tap is
 // permuted so that (iu, iw, im) index the coordinates that become sc and tc and the major coordinate.
-template <int AXIS, bool TILED, bool POW2>
+template <int AXIS, bool TILED, bool POW2, bool X25>
 VKR_DEV float taps_one_face(const float *face_base, int res, const float (&X)[3], const float (&Y)[3], const float (&Z)[3], float cur)
 {
     const float fres = (float)res;
@@ -211,7 +211,8 @@ VKR_DEV float taps_one_face(const float *face_base, int res, const float (&X)[3]
         unsigned off;                                                                    \
         if (TILED) asm("v_lshl_add_u32 %0, %1, 5, %2" : "=v"(off) : "v"(J[iw][im]), "v"(I[iu][im])); \
         else off = __umul24(J[iw][im], row_unit) + I[iu][im];                            \
-        const float closest = *(const float *)(base + off) * 25.0f;                      \
+        const float stored = *(const float *)(base + off);                               \
+        const float closest = X25 ? stored : stored * 25.0f;  /* X25: the map holds the product */ \
         count += step_closer(closest, cur_s);                                            \
     }
     VKR_GRID20A(VKR_TAP)
@@ -271,7 +272,7 @@ VKR_DEV void tap_offsets_of_axis(int res, unsigned face_shift, const float (&X)[
 #undef VKR_TAP
 }
 
-template <bool TILED, bool POW2>
+template <bool TILED, bool POW2, bool X25>
 VKR_DEV float taps_any_face(const float *cube, int res, const float (&X)[3], const float (&Y)[3], const float (&Z)[3], float cur,
                             bool has_x, bool has_y, bool has_z)
 {
@@ -294,9 +295,9 @@ VKR_DEV float taps_any_face(const float *cube, int res, const float (&X)[3], con
     const float cur_s = cur * 0x1p60f;
     float count_a = 0.0f, count_b = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 10; k++) count_a += step_closer(*(const float *)(base + off[k]) * 25.0f, cur_s);
+    for (int k = 0; k < 10; k++) count_a += step_closer(X25 ? *(const float *)(base + off[k]) : *(const float *)(base + off[k]) * 25.0f, cur_s);
 #pragma unroll
-    for (int k = 10; k < 20; k++) count_b += step_closer(*(const float *)(base + off[k]) * 25.0f, cur_s);
+    for (int k = 10; k < 20; k++) count_b += step_closer(X25 ? *(const float *)(base + off[k]) : *(const float *)(base + off[k]) * 25.0f, cur_s);
     return count_a + count_b;
 }
 
@@ -379,9 +380,11 @@ VKR_DEV void tile_of_block(unsigned b, int tiles_x, int tiles_y, int &tx, int &t
 // ran 25 % slower for instruction-cache misses alone.
 // MASKED: each light's draw touches only the pixels its light volume covers (one 64-bit mask per
 // light and tile, bit = lane); a light that covers none of the wave's pixels is skipped whole.
-template <bool TILED, bool POW2, bool MASKED>
+// LAYOUT: VKR_CUBE_LAYOUT_* of the point-shadow cubes.
+template <int LAYOUT, bool POW2, bool MASKED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void shade_kernel(const ShadeParams p)
 {
+    constexpr bool TILED = LAYOUT != VKR_CUBE_LAYOUT_LINEAR, X25 = LAYOUT == VKR_CUBE_LAYOUT_TILED_8X4_X25;
     // one wave per workgroup, one 8x8-pixel tile per wave
     const int lane = threadIdx.x;
     int tile_x, tile_y;
@@ -526,12 +529,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             float count;
             if (face0 >= 0) {
                 const float *fb = cube + (size_t)face0 * face_stride;
-                if (face0 >= 4) count = taps_one_face<2, TILED, POW2>(fb, p.cube_res, X, Y, Z, cur);
-                else if (face0 >= 2) count = taps_one_face<1, TILED, POW2>(fb, p.cube_res, X, Y, Z, cur);
-                else count = taps_one_face<0, TILED, POW2>(fb, p.cube_res, X, Y, Z, cur);
+                if (face0 >= 4) count = taps_one_face<2, TILED, POW2, X25>(fb, p.cube_res, X, Y, Z, cur);
+                else if (face0 >= 2) count = taps_one_face<1, TILED, POW2, X25>(fb, p.cube_res, X, Y, Z, cur);
+                else count = taps_one_face<0, TILED, POW2, X25>(fb, p.cube_res, X, Y, Z, cur);
             } else {  // the wave straddles a cube edge or corner
                 const unsigned axes = wave_major_axes(Fv.x, Fv.y, Fv.z, disk);
-                count = taps_any_face<TILED, POW2>(cube, p.cube_res, X, Y, Z, cur, axes & 1u, axes & 2u, axes & 4u);
+                count = taps_any_face<TILED, POW2, X25>(cube, p.cube_res, X, Y, Z, cur, axes & 1u, axes & 2u, axes & 4u);
             }
             // all 20 taps in shadow: the factor 1 - 20/20 is an exact zero, same argument
             if ((live & (__builtin_amdgcn_ballot_w64(slow_domain) | __builtin_amdgcn_ballot_w64(count < 20.0f))) == 0ull) continue;
@@ -573,6 +576,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
 
 // Row-major face -> 8x4-texel tiles.  Eight lanes move one tile (16 bytes each), so a wave writes
 // eight consecutive tiles (1 KiB contiguous) and reads four 256-byte row segments.
+// X25: the tiles hold RN(25 * depth).
+template <bool X25>
 __global__ __launch_bounds__(256) void tile_depth_kernel(const float4 *src, float4 *dst, int res, unsigned tiles_per_face, unsigned total_tiles)
 {
     const unsigned t = (blockIdx.x * 256u + threadIdx.x) >> 3;  // tile index over all faces
@@ -582,25 +587,36 @@ __global__ __launch_bounds__(256) void tile_depth_kernel(const float4 *src, floa
     const unsigned tiles_x = (unsigned)res >> 3;
     const unsigned ty = tf / tiles_x, tx = tf - ty * tiles_x;
     const size_t texel = (size_t)face * res * res + (size_t)(ty * 4u + (q >> 1)) * res + tx * 8u + (q & 1u) * 4u;
-    dst[(size_t)t * 8u + q] = src[texel >> 2];
+    float4 v = src[texel >> 2];
+    if (X25) { v.x *= 25.0f; v.y *= 25.0f; v.z *= 25.0f; v.w *= 25.0f; }
+    dst[(size_t)t * 8u + q] = v;
 }
 
 }  // namespace vkr
 
-extern "C" int32_t vkr_tile_depth_cubes(const float *linear, float *tiled, int32_t n_faces, int32_t res, void *stream)
+extern "C" int32_t vkr_relayout_depth_cubes(const float *linear, float *tiled, int32_t n_faces, int32_t res, int32_t layout, void *stream)
 {
     using namespace vkr;
-    VKR_REQUIRE(linear && tiled, "vkr_tile_depth_cubes: an image is null");
-    VKR_REQUIRE(n_faces >= 0 && res > 0 && res % 8 == 0 && res <= 8192, "vkr_tile_depth_cubes: %d faces of size %d (size must be a multiple of 8, at most 8192)", n_faces, res);
+    VKR_REQUIRE(linear && tiled, "vkr_relayout_depth_cubes: an image is null");
+    VKR_REQUIRE(layout == VKR_CUBE_LAYOUT_TILED_8X4 || layout == VKR_CUBE_LAYOUT_TILED_8X4_X25, "vkr_relayout_depth_cubes: layout %d is not a tiled one", layout);
+    VKR_REQUIRE(n_faces >= 0 && res > 0 && res % 8 == 0 && res <= 8192, "vkr_relayout_depth_cubes: %d faces of size %d (size must be a multiple of 8, at most 8192)", n_faces, res);
     const size_t bytes = (size_t)n_faces * res * res * 4;
     const char *a = (const char *)linear, *b = (const char *)tiled;
-    VKR_REQUIRE(a + bytes <= b || b + bytes <= a, "vkr_tile_depth_cubes: source and destination overlap");
+    VKR_REQUIRE(a + bytes <= b || b + bytes <= a, "vkr_relayout_depth_cubes: source and destination overlap");
     const uint64_t tiles_per_face = (uint64_t)(res / 8) * (res / 4), total = tiles_per_face * (uint64_t)n_faces;
-    VKR_REQUIRE(total < (1ull << 28), "vkr_tile_depth_cubes: too many texels for one call");
+    VKR_REQUIRE(total < (1ull << 28), "vkr_relayout_depth_cubes: too many texels for one call");
     if (total == 0) return VKR_OK;
-    hipLaunchKernelGGL(tile_depth_kernel, dim3((unsigned)((total * 8 + 255) / 256)), dim3(256), 0, as_stream(stream),
-                       (const float4 *)linear, (float4 *)tiled, res, (unsigned)tiles_per_face, (unsigned)total);
-    return launch_status("vkr_tile_depth_cubes");
+    const dim3 grid((unsigned)((total * 8 + 255) / 256));
+    if (layout == VKR_CUBE_LAYOUT_TILED_8X4_X25)
+        hipLaunchKernelGGL(tile_depth_kernel<true>, grid, dim3(256), 0, as_stream(stream), (const float4 *)linear, (float4 *)tiled, res, (unsigned)tiles_per_face, (unsigned)total);
+    else
+        hipLaunchKernelGGL(tile_depth_kernel<false>, grid, dim3(256), 0, as_stream(stream), (const float4 *)linear, (float4 *)tiled, res, (unsigned)tiles_per_face, (unsigned)total);
+    return launch_status("vkr_relayout_depth_cubes");
+}
+
+extern "C" int32_t vkr_tile_depth_cubes(const float *linear, float *tiled, int32_t n_faces, int32_t res, void *stream)
+{
+    return vkr_relayout_depth_cubes(linear, tiled, n_faces, res, VKR_CUBE_LAYOUT_TILED_8X4, stream);
 }
 
 extern "C" int32_t vkr_shade(const VkrShadeArgs *a, void *stream)
@@ -617,7 +633,7 @@ extern "C" int32_t vkr_shade(const VkrShadeArgs *a, void *stream)
     VKR_REQUIRE((int64_t)a->dir_res * a->dir_res < (1ll << 31), "vkr_shade: directional shadow map too large");
     VKR_REQUIRE(a->coverage_mode == VKR_COVERAGE_FULLSCREEN || a->coverage_mode == VKR_COVERAGE_MESH, "vkr_shade: unknown coverage mode %d", a->coverage_mode);
     VKR_REQUIRE(a->coverage_mode != VKR_COVERAGE_MESH || a->n_lights == 0 || a->coverage_masks, "vkr_shade: VKR_COVERAGE_MESH needs coverage_masks (see vkr_light_coverage)");
-    VKR_REQUIRE(a->cube_layout == VKR_CUBE_LAYOUT_LINEAR || a->cube_layout == VKR_CUBE_LAYOUT_TILED_8X4, "vkr_shade: unknown cube shadow layout %d", a->cube_layout);
+    VKR_REQUIRE(a->cube_layout >= VKR_CUBE_LAYOUT_LINEAR && a->cube_layout <= VKR_CUBE_LAYOUT_TILED_8X4_X25, "vkr_shade: unknown cube shadow layout %d", a->cube_layout);
     VKR_REQUIRE(a->cube_layout == VKR_CUBE_LAYOUT_LINEAR || a->n_lights == 0 || a->cube_res % 8 == 0, "vkr_shade: the tiled cube shadow layout needs a face size that is a multiple of 8 (got %d)", a->cube_res);
 
     ShadeParams p;
@@ -642,13 +658,14 @@ extern "C" int32_t vkr_shade(const VkrShadeArgs *a, void *stream)
     p.tiles_x = (a->width + 7) / 8; p.tiles_y = (a->rows + 7) / 8;
     VKR_REQUIRE((int64_t)p.tiles_x * p.tiles_y < (1ll << 31), "vkr_shade: strip too large");
     const dim3 grid((unsigned)(p.tiles_x * p.tiles_y));
-    const bool tiled = a->cube_layout == VKR_CUBE_LAYOUT_TILED_8X4;
     const bool pow2 = a->n_lights > 0 && (a->cube_res & (a->cube_res - 1)) == 0;
     const bool masked = p.coverage != nullptr;
     typedef void (*kernel_t)(const ShadeParams);
-    static const kernel_t kernels[8] = {shade_kernel<false, false, false>, shade_kernel<false, false, true>, shade_kernel<false, true, false>, shade_kernel<false, true, true>,
-                                        shade_kernel<true, false, false>,  shade_kernel<true, false, true>,  shade_kernel<true, true, false>,  shade_kernel<true, true, true>};
-    const kernel_t kernel = kernels[(tiled ? 4 : 0) + (pow2 ? 2 : 0) + (masked ? 1 : 0)];
+    static const kernel_t kernels[12] = {
+        shade_kernel<0, false, false>, shade_kernel<0, false, true>, shade_kernel<0, true, false>, shade_kernel<0, true, true>,
+        shade_kernel<1, false, false>, shade_kernel<1, false, true>, shade_kernel<1, true, false>, shade_kernel<1, true, true>,
+        shade_kernel<2, false, false>, shade_kernel<2, false, true>, shade_kernel<2, true, false>, shade_kernel<2, true, true>};
+    const kernel_t kernel = kernels[a->cube_layout * 4 + (pow2 ? 2 : 0) + (masked ? 1 : 0)];
     hipLaunchKernelGGL(kernel, grid, dim3(64), 0, as_stream(stream), p);
     return launch_status("vkr_shade");
 }

@@ -25,7 +25,7 @@ struct ShadowParams {
     float model[16];
     const float *lights;  // VkrLightInfo array viewed as floats (point) or null (directional)
     float light_space[16];  // directional: lightSpaceMatrix
-    int res; float far_plane; int tiled;
+    int res; float far_plane; int tiled; float store_scale;  // store_scale: 25 for VKR_CUBE_LAYOUT_TILED_8X4_X25, else 1
     float *out;
 };
 
@@ -59,7 +59,7 @@ VKR_DEV size_t depth_texel_index(int res, int i, int j, bool tiled)
 // through `have`: all lanes of a call target the same image).  POINT: world = corners' world positions
 // and the depth is point_shadow.frag's; otherwise the fixed-function z / w.
 template <bool POINT>
-VKR_DEV void shadow_raster(bool valid, const float (&clip)[3][4], const float (&world)[3][4], const float *light_pos, float inv_far, int res, bool tiled, float *img)
+VKR_DEV void shadow_raster(bool valid, const float (&clip)[3][4], const float (&world)[3][4], const float *light_pos, float inv_far, int res, bool tiled, float store_scale, float *img)
 {
     int bx0 = 0, by0 = 0, bx1 = -1, by1 = -1;
     bool have = valid && !clip_reject(clip);
@@ -88,8 +88,11 @@ VKR_DEV void shadow_raster(bool valid, const float (&clip)[3][4], const float (&
         } else {
             depth = (float)(zs * t.inv_D) + 0.0f;  // z / w of the fixed-function pipeline as z * (1/w) (-0 becomes +0)
         }
-        if (depth < 1.0f)  // CompareOp.Less against the cleared 1.0 and every earlier write; depth >= 0 here
-            atomicMin((unsigned int *)(img + depth_texel_index(res, i, j, tiled)), __builtin_bit_cast(unsigned int, depth));
+        // CompareOp.Less against the cleared 1.0 and every earlier write; depth >= 0 here.  The stored value may be
+        // the product with 25 the shading pass forms: rounding is monotonic, so the minimum of the products is the
+        // product of the minimum.
+        if (depth < 1.0f)
+            atomicMin((unsigned int *)(img + depth_texel_index(res, i, j, tiled)), __builtin_bit_cast(unsigned int, depth * store_scale));
     });
 }
 
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256) void point_shadow_kernel(const ShadowParams p)
         float clip[3][4];
 #pragma unroll
         for (int k = 0; k < 3; k++) mat4_vec4(s_m[face], world[k], clip[k]);  // point_shadow.geom:20
-        shadow_raster<true>(valid, clip, world, eye, inv_far, p.res, p.tiled != 0, p.out + ((size_t)li * 6 + face) * face_texels);
+        shadow_raster<true>(valid, clip, world, eye, inv_far, p.res, p.tiled != 0, p.store_scale, p.out + ((size_t)li * 6 + face) * face_texels);
     }
 }
 
@@ -140,13 +143,13 @@ __global__ __launch_bounds__(256) void dir_shadow_kernel(const ShadowParams p)
             mat4_vec4(s_mvp, v4, clip[k]);
         }
     }
-    shadow_raster<false>(valid, clip, clip, nullptr, 0.0f, p.res, false, p.out);
+    shadow_raster<false>(valid, clip, clip, nullptr, 0.0f, p.res, false, 1.0f, p.out);
 }
 
-__global__ __launch_bounds__(256) void fill_depth_kernel(float4 *out, size_t n4)
+__global__ __launch_bounds__(256) void fill_depth_kernel(float4 *out, size_t n4, float value)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n4) out[i] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    if (i < n4) out[i] = make_float4(value, value, value, value);
 }
 
 static int32_t check_draws(const char *who, const VkrMeshDraw *draws, int32_t n_draws)
@@ -174,14 +177,15 @@ extern "C" int32_t vkr_point_shadow_maps(const VkrPointShadowArgs *a, void *stre
     VKR_REQUIRE(a->n_lights >= 0 && a->n_lights <= 65535 && (a->n_lights == 0 || a->lights), "vkr_point_shadow_maps: lights missing or too many");
     VKR_REQUIRE(a->res > 0 && a->res <= 8192 && a->res % 2 == 0, "vkr_point_shadow_maps: face size %d (even, at most 8192)", a->res);
     VKR_REQUIRE(a->far_plane > 1.0f, "vkr_point_shadow_maps: far plane %g must lie beyond the near plane at 1", (double)a->far_plane);
-    VKR_REQUIRE(a->layout == VKR_CUBE_LAYOUT_LINEAR || (a->layout == VKR_CUBE_LAYOUT_TILED_8X4 && a->res % 8 == 0), "vkr_point_shadow_maps: layout %d not usable with face size %d", a->layout, a->res);
+    VKR_REQUIRE(a->layout == VKR_CUBE_LAYOUT_LINEAR || ((a->layout == VKR_CUBE_LAYOUT_TILED_8X4 || a->layout == VKR_CUBE_LAYOUT_TILED_8X4_X25) && a->res % 8 == 0), "vkr_point_shadow_maps: layout %d not usable with face size %d", a->layout, a->res);
     VKR_REQUIRE(a->out != nullptr, "vkr_point_shadow_maps: output is null");
     if (a->n_lights == 0) return VKR_OK;
     const size_t n4 = (size_t)a->n_lights * 6 * a->res * a->res / 4;
-    hipLaunchKernelGGL(fill_depth_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, as_stream(stream), (float4 *)a->out, n4);  // clear value 1.0
+    const float scale = a->layout == VKR_CUBE_LAYOUT_TILED_8X4_X25 ? 25.0f : 1.0f;
+    hipLaunchKernelGGL(fill_depth_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, as_stream(stream), (float4 *)a->out, n4, scale);  // clear value 1.0
     ShadowParams p;
     p.lights = (const float *)a->lights;
-    p.res = a->res; p.far_plane = a->far_plane; p.tiled = a->layout == VKR_CUBE_LAYOUT_TILED_8X4; p.out = a->out;
+    p.res = a->res; p.far_plane = a->far_plane; p.tiled = a->layout != VKR_CUBE_LAYOUT_LINEAR; p.store_scale = scale; p.out = a->out;
     for (int i = 0; i < 16; i++) p.light_space[i] = 0.0f;
     for (int d = 0; d < a->n_draws; d++) {
         if (a->draws[d].n_tris == 0) continue;
@@ -200,10 +204,10 @@ extern "C" int32_t vkr_dir_shadow_map(const VkrDirShadowArgs *a, void *stream)
     VKR_REQUIRE(a->res > 0 && a->res <= 16384 && a->res % 2 == 0, "vkr_dir_shadow_map: map size %d (even, at most 16384)", a->res);
     VKR_REQUIRE(a->out != nullptr, "vkr_dir_shadow_map: output is null");
     const size_t n4 = (size_t)a->res * a->res / 4;
-    hipLaunchKernelGGL(fill_depth_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, as_stream(stream), (float4 *)a->out, n4);
+    hipLaunchKernelGGL(fill_depth_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, as_stream(stream), (float4 *)a->out, n4, 1.0f);
     ShadowParams p;
     p.lights = nullptr;
-    p.res = a->res; p.far_plane = 0.0f; p.tiled = 0; p.out = a->out;
+    p.res = a->res; p.far_plane = 0.0f; p.tiled = 0; p.store_scale = 1.0f; p.out = a->out;
     for (int i = 0; i < 16; i++) p.light_space[i] = a->light_space[i];
     for (int d = 0; d < a->n_draws; d++) {
         if (a->draws[d].n_tris == 0) continue;

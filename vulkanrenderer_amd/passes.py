@@ -38,6 +38,12 @@ def f16_bits(t: torch.Tensor) -> np.ndarray:
     return t.detach().cpu().numpy().view(np.uint16)
 
 
+def _cube_layout_for(tiled: bool | None, res: int) -> int:
+    if tiled is None:
+        return _lib.CUBE_LAYOUT_TILED_8X4_X25 if res % 8 == 0 else _lib.CUBE_LAYOUT_LINEAR
+    return _lib.CUBE_LAYOUT_TILED_8X4 if tiled else _lib.CUBE_LAYOUT_LINEAR
+
+
 @dataclasses.dataclass
 class DeviceFrame:
     """A frame's inputs resident in HBM (what the geometry / shadow passes would have left there)."""
@@ -61,13 +67,13 @@ class DeviceFrame:
 
     @staticmethod
     def upload(f: FrameInputs, device, tiled: bool | None = None) -> "DeviceFrame":
-        """`tiled`: store the point-shadow cubes as 8x4-texel tiles (None: whenever the face size allows)."""
+        """`tiled`: how the point-shadow cubes are stored -- None: the layout the shading kernel is fastest on
+        (8x4-texel tiles of 25 * depth) whenever the face size allows; True: 8x4-texel tiles; False: rows."""
         d = DeviceFrame._upload_linear(f, device)
-        if tiled is None:
-            tiled = d.cube_shadow.shape[-1] % 8 == 0
-        if tiled and d.n_lights > 0:
-            d.cube_shadow = tile_depth_cubes(d.cube_shadow)
-            d.cube_layout = _lib.CUBE_LAYOUT_TILED_8X4
+        layout = _cube_layout_for(tiled, d.cube_shadow.shape[-1])
+        if layout != _lib.CUBE_LAYOUT_LINEAR and d.n_lights > 0:
+            d.cube_shadow = tile_depth_cubes(d.cube_shadow, layout)
+            d.cube_layout = layout
         return d
 
     @staticmethod
@@ -114,17 +120,15 @@ def _mesh_draws(draws):
 def point_shadow_maps(draws, lights: torch.Tensor, n_lights: int, res: int, far_plane: float = 25.0,
                       tiled: bool | None = None) -> tuple[torch.Tensor, int]:
     """The point-shadow passes: (depth cubes float32 [n_lights, 6, res, res], layout).  `lights` is the
-    device LightInfo array of a DeviceFrame; `tiled` None: 8x4-texel tiles whenever res allows."""
+    device LightInfo array of a DeviceFrame; `tiled` as in DeviceFrame.upload."""
     lib = _lib.load()
-    if tiled is None:
-        tiled = res % 8 == 0
     out = torch.empty((n_lights, 6, res, res), dtype=torch.float32, device=lights.device)
     arr = _mesh_draws(draws)
     a = _lib.PointShadowArgs()
     a.draws, a.n_draws = arr, len(draws)
     a.lights, a.n_lights = _ptr(lights), n_lights
     a.res, a.far_plane = res, far_plane
-    a.layout = _lib.CUBE_LAYOUT_TILED_8X4 if tiled else _lib.CUBE_LAYOUT_LINEAR
+    a.layout = _cube_layout_for(tiled, res)
     a.out = _ptr(out)
     _lib.check(lib.vkr_point_shadow_maps(C.byref(a), _stream()))
     return out, a.layout
@@ -187,12 +191,13 @@ def skybox(env: torch.Tensor, scene: np.ndarray, width: int, rows: int, frame_ro
     return out
 
 
-def tile_depth_cubes(linear: torch.Tensor) -> torch.Tensor:
-    """[..., res, res] float32 depth faces, row-major -> the same faces as 8x4-texel tiles (new tensor)."""
+def tile_depth_cubes(linear: torch.Tensor, layout: int = _lib.CUBE_LAYOUT_TILED_8X4) -> torch.Tensor:
+    """[..., res, res] float32 depth faces, row-major -> the same faces as 8x4-texel tiles (new tensor), holding
+    the depth (CUBE_LAYOUT_TILED_8X4) or 25 * depth (CUBE_LAYOUT_TILED_8X4_X25)."""
     lib = _lib.load()
     res = linear.shape[-1]
     out = torch.empty_like(linear)
-    _lib.check(lib.vkr_tile_depth_cubes(_ptr(linear), _ptr(out), linear.numel() // (res * res), res, _stream()))
+    _lib.check(lib.vkr_relayout_depth_cubes(_ptr(linear), _ptr(out), linear.numel() // (res * res), res, layout, _stream()))
     return out
 
 
