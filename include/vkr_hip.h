@@ -338,8 +338,8 @@ VKR_EXPORT int32_t vkr_draw_model(vkr_ctx *ctx, int32_t mesh, int32_t material, 
 /* Images of passes the frame does not render itself (see vkr_draw_model), for the current frame. */
 VKR_EXPORT int32_t vkr_upload_gbuffer(vkr_ctx *ctx, const void *albedo, const void *normal, const void *arm, const void *position);
 /* An image in place of the skybox draw (VulkanRenderer.cs:436-443) for the current frame.  Without one, EndFrame
- * draws the skybox from the environment cube when there is one (vkr_create_skybox_cubemap / vkr_upload_env_cube);
- * with neither, texels the composition draw discards stay (0,0,0,1). */
+ * draws the skybox from the environment cube when there is one (vkr_create_skybox_cubemap / vkr_upload_env_cube)
+ * and the frame's projection matrix has x and y scales; otherwise texels the composition draw discards stay (0,0,0,1). */
 VKR_EXPORT int32_t vkr_upload_background(vkr_ctx *ctx, const void *rgba16f_or_null);
 VKR_EXPORT int32_t vkr_upload_dir_shadow(vkr_ctx *ctx, const float *depth);
 VKR_EXPORT int32_t vkr_upload_point_shadow(vkr_ctx *ctx, int32_t light, const float *depth_cube);

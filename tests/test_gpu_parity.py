@@ -965,3 +965,29 @@ def test_shade_with_non_finite_and_huge_inputs(gpu, oracle):
         got_c, got_t = P.f16_bits(color), P.f16_bits(thr)
         assert_bits_equal(got_c[finite], want_c[finite], f"colour of the finite pixels (tiled cubes: {tiled})")
         assert_bits_equal(got_t[finite], want_t[finite], f"threshold of the finite pixels (tiled cubes: {tiled})")
+
+
+def test_renderer_without_a_projection_draws_no_skybox(gpu, oracle):
+    """A SceneInfo whose projection matrix is all zero (never set): EndFrame leaves the discarded texels at the
+    clear colour instead of failing on the skybox draw."""
+    from vulkanrenderer_amd.renderer import HipRenderer
+    w, h, nl = 64, 40, 1
+    f = synth.make_frame(99, w, h, nl, 16, 64, irr_res=8, pref_res=16, lut_res=32)
+    f.scene = f.scene.copy()
+    f.scene["camera_projection"] = np.zeros(16, dtype=np.float32)
+    with HipRenderer(w, h, max_lights=2, dir_shadow_res=64, point_shadow_res=16, env_res=16,
+                     irradiance_res=8, prefilter_res=16, prefilter_mips=1, brdf_lut_res=32) as r:
+        r.UploadEnvironmentCubemap(synth.make_env_cube(np.random.default_rng(2), 16))
+        r.CreateIrradianceCubemap(); r.CreatePrefilteredCubemap(); r.CreateBRDFLUTTexture()
+        f.irradiance = r.Read(_lib.TARGET_IRRADIANCE)
+        f.prefilter = r.Read(_lib.TARGET_PREFILTER, mip=0)
+        f.brdf_lut = r.Read(_lib.TARGET_BRDF_LUT)
+        r.UpdateSceneInfo(f.scene)
+        r.UploadGBuffer(f.albedo, f.normal, f.arm, f.position)
+        r.UploadDirectionalShadowMap(f.dir_shadow)
+        r.UploadPointShadowMap(0, f.cube_shadow[0])
+        r.SetLightInfos(f.lights)
+        r.BeginFrame()
+        r._call(r._lib.vkr_end_frame)
+        want_c, _ = oracle.shade(f)
+        assert_bits_equal(r.Read(_lib.TARGET_COLOR, 0), want_c, "colour")

@@ -134,6 +134,13 @@ static int32_t run_skybox(vkr_ctx *c, Frame &f);
     VKR_REQUIRE((c) != nullptr, "%s: context is null", __func__);    \
     VKR_HIP_CHECK(hipSetDevice((c)->cfg.device))
 
+// The skybox is drawn when there is an environment cube, no uploaded background for the frame, and a camera
+// whose projection has x and y scales (a zeroed SceneInfo has none: nothing to look through).
+static bool draws_skybox(const vkr_ctx *c, const Frame &f)
+{
+    return !f.has_background && c->have_env && f.scene.camera_projection[0] != 0.0f && f.scene.camera_projection[5] != 0.0f;
+}
+
 static int32_t fill_shade_args(vkr_ctx *c, Frame &f, VkrShadeArgs &a)
 {
     if (!(c->have_irr && c->have_pref && c->have_lut))
@@ -141,7 +148,7 @@ static int32_t fill_shade_args(vkr_ctx *c, Frame &f, VkrShadeArgs &a)
     memset(&a, 0, sizeof(a));
     a.width = c->cfg.width; a.rows = c->cfg.height;
     a.albedo = f.gbuf[0]; a.normal = f.gbuf[1]; a.arm = f.gbuf[2]; a.position = f.gbuf[3];
-    a.background = f.has_background || c->have_env ? f.background : nullptr;  // uploaded, or drawn by run_skybox
+    a.background = f.has_background || draws_skybox(c, f) ? f.background : nullptr;  // uploaded, or drawn by run_skybox
     a.scene = f.scene;
     a.lights = f.lights; a.n_lights = f.n_lights; a.coverage_mode = f.coverage;
     a.dir_shadow = f.dir_shadow; a.dir_res = c->cfg.dir_shadow_res;
@@ -230,7 +237,7 @@ static int32_t run_coverage(vkr_ctx *c, Frame &f)
 // An image given with vkr_upload_background for this frame takes its place.
 static int32_t run_skybox(vkr_ctx *c, Frame &f)
 {
-    if (f.has_background || !c->have_env) return VKR_OK;
+    if (!draws_skybox(c, f)) return VKR_OK;
     const void *env = c->env_tiled ? c->env_tiled : c->env;
     const int32_t layout = c->env_tiled ? VKR_ENV_LAYOUT_TILED_4X4 : VKR_ENV_LAYOUT_LINEAR;
     return vkr_skybox(env, c->cfg.env_res, layout, &f.scene, c->cfg.width, c->cfg.height, c->cfg.height, 0, f.background, c->stream);
