@@ -80,14 +80,36 @@ __global__ __launch_bounds__(256) void coverage_kernel(const CoverageParams p)
     const int lx = lane & 7, ly = lane >> 3;
     unsigned long long covered = 0;  // bit k: this lane's pixel of tile k is covered
 
+    // the indices of the next round's triangle are fetched while this round is worked on: the kernel is bound by
+    // the latency of its few dependent loads, not by arithmetic
+    unsigned nidx[3] = {0u, 0u, 0u};
+    if (tid < p.n_tris) { nidx[0] = p.indices[3 * tid]; nidx[1] = p.indices[3 * tid + 1]; nidx[2] = p.indices[3 * tid + 2]; }
     for (int t0 = 0; t0 < p.n_tris; t0 += 256) {
         if (tid == 0) s_count = 0;
         __syncthreads();
         const int t = t0 + tid;
+        const unsigned idx[3] = {nidx[0], nidx[1], nidx[2]};
+        if (t + 256 < p.n_tris) { nidx[0] = p.indices[3 * (t + 256)]; nidx[1] = p.indices[3 * (t + 256) + 1]; nidx[2] = p.indices[3 * (t + 256) + 2]; }
         if (t < p.n_tris) {
             // an index past the vertex array would read outside LDS: clamp it
             const unsigned vmax = (unsigned)p.n_verts - 1u;
-            const float4 c0 = s_clip[min(p.indices[3 * t], vmax)], c1 = s_clip[min(p.indices[3 * t + 1], vmax)], c2 = s_clip[min(p.indices[3 * t + 2], vmax)];
+            const float4 c0 = s_clip[min(idx[0], vmax)], c1 = s_clip[min(idx[1], vmax)], c2 = s_clip[min(idx[2], vmax)];
+            // Cheap binary32 rejections before the binary64 set-up (they only ever drop triangles the exact test
+            // below would drop for every pixel of the block): the triangle lies outside one plane of the clip
+            // volume, or -- all three corners in front of the eye -- its bounding box in normalised device
+            // coordinates, widened by 1e-4 (a fifth of a 4K pixel; the divisions are good to 1e-6), misses the block.
+            bool reject = (c0.x > c0.w && c1.x > c1.w && c2.x > c2.w) || (c0.x < -c0.w && c1.x < -c1.w && c2.x < -c2.w) ||
+                          (c0.y > c0.w && c1.y > c1.w && c2.y > c2.w) || (c0.y < -c0.w && c1.y < -c1.w && c2.y < -c2.w) ||
+                          (c0.z < 0.0f && c1.z < 0.0f && c2.z < 0.0f);
+            if (!reject && c0.w > 1e-6f && c1.w > 1e-6f && c2.w > 1e-6f) {
+                const float i0 = 1.0f / c0.w, i1 = 1.0f / c1.w, i2 = 1.0f / c2.w;
+                const float ax = c0.x * i0, bx = c1.x * i1, cx = c2.x * i2, ay = c0.y * i0, by = c1.y * i1, cy = c2.y * i2;
+                const float pad = 1e-4f + 1e-5f * fmaxf(fmaxf(fabsf(ax), fabsf(bx)), fmaxf(fmaxf(fabsf(cx), fabsf(ay)), fmaxf(fabsf(by), fabsf(cy))));
+                reject = fminf(ax, fminf(bx, cx)) - pad > (float)xb || fmaxf(ax, fmaxf(bx, cx)) + pad < (float)xa ||
+                         fminf(ay, fminf(by, cy)) - pad > (float)yb || fmaxf(ay, fmaxf(by, cy)) + pad < (float)ya;
+            }
+            if (reject) goto next_triangle;
+            {
             const double x0 = c0.x, y0 = c0.y, w0 = c0.w, x1 = c1.x, y1 = c1.y, w1 = c1.w, x2 = c2.x, y2 = c2.y, w2 = c2.w;
             CovTri tr;
             tr.a[0] = y1 * w2 - w1 * y2; tr.b[0] = w1 * x2 - x1 * w2; tr.c[0] = x1 * y2 - y1 * x2;
@@ -100,6 +122,8 @@ __global__ __launch_bounds__(256) void coverage_kernel(const CoverageParams p)
             for (int i = 0; i < 3; i++)  // an edge with all four corners outside rules the block out
                 keep = keep && !(cov_edge(tr, i, xa, ya) < 0.0 && cov_edge(tr, i, xb, ya) < 0.0 && cov_edge(tr, i, xa, yb) < 0.0 && cov_edge(tr, i, xb, yb) < 0.0);
             if (keep) s_tri[atomicAdd(&s_count, 1)] = tr;
+            }
+        next_triangle:;
         }
         __syncthreads();
         const int count = s_count;
@@ -155,14 +179,20 @@ __global__ __launch_bounds__(256) void coverage_kernel(const CoverageParams p)
         __syncthreads();  // the list is rebuilt by the next round
     }
 
+    // bit k of `covered` in lane l -> bit l of tile k's mask: 64 ballots, lane k keeping the k-th, then one
+    // store per lane instead of 64 single-lane stores per wave
     unsigned long long *masks = p.masks + (size_t)li * p.tiles_x * p.tiles_y;
+    unsigned long long mine = 0;
     for (int k = 0; k < 64; k++) {
         const int tile = wave * 64 + k;
-        const int tx = (bx0 >> 3) + (tile & 15), ty = (by0 >> 3) + (tile >> 4);
-        if (tx >= p.tiles_x || ty >= p.tiles_y) continue;
         const int x = bx0 + (tile & 15) * 8 + lx, y = by0 + (tile >> 4) * 8 + ly;
         const unsigned long long m = __ballot(((covered >> k) & 1ull) && x < bx1 && y < by1);
-        if (lane == 0) masks[(size_t)ty * p.tiles_x + tx] = m;
+        if (lane == k) mine = m;
+    }
+    {
+        const int tile = wave * 64 + lane;
+        const int tx = (bx0 >> 3) + (tile & 15), ty = (by0 >> 3) + (tile >> 4);
+        if (tx < p.tiles_x && ty < p.tiles_y) masks[(size_t)ty * p.tiles_x + tx] = mine;
     }
 }
 
