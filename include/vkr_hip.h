@@ -199,7 +199,9 @@ typedef struct VkrGpassDraw {
     VkrTexture albedo, normal, arm;  /* Model.Material */
 } VkrGpassDraw;
 typedef struct VkrGpassArgs {
-    const VkrGpassDraw *draws; int32_t n_draws;  /* host array, in submission order */
+    const VkrGpassDraw *draws; int32_t n_draws;  /* host array, in submission order; copied to the device by an
+                                                    asynchronous copy on `stream`: pageable memory may be reused when the
+                                                    call returns, pinned memory must stay valid until the stream gets there */
     VkrSceneInfo scene;                          /* camera_view and camera_projection are read */
     int32_t width, rows;                         /* the image: a strip of the frame */
     int32_t frame_rows, row0;
@@ -208,6 +210,18 @@ typedef struct VkrGpassArgs {
 } VkrGpassArgs;
 VKR_EXPORT int64_t vkr_gbuffer_workspace_bytes(int32_t width, int32_t rows, int32_t n_draws);
 VKR_EXPORT int32_t vkr_gbuffer(const VkrGpassArgs *args, void *stream);
+
+/* vkr_gbuffer for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  The visibility keys and
+ * the draw records live in a fixed array inside the library's code object instead of a workspace
+ * (args->workspace and args->workspace_bytes are ignored), so the call allocates and frees nothing; each GPU
+ * the library is loaded on holds VKR_GBUFFER_STATIC_MAX_PIXELS * 8 bytes + 16 KiB for it until the process
+ * ends.  Results equal vkr_gbuffer's bit for bit.  Limits: width * rows <= VKR_GBUFFER_STATIC_MAX_PIXELS and
+ * n_draws <= VKR_GBUFFER_STATIC_MAX_DRAWS, otherwise VKR_ERR_INVALID.  All calls on one GPU share the array:
+ * calls that overlap in time on one GPU (two streams, two threads) race; calls on one stream do not. */
+#define VKR_GBUFFER_STATIC_MAX_PIXELS 2097152 /* 1920 x 1080 fits */
+#define VKR_GBUFFER_STATIC_MAX_DRAWS 64
+VKR_EXPORT int32_t vkr_gbuffer_static(const VkrGpassArgs *args, void *stream);
 
 /* Replaces the skybox draw that opens the composition pass (VulkanRenderer.cs:436-443; cubemap.vert, skybox.frag):
  * colour = texture(skybox cube, view ray of the pixel), alpha 1.  The result is the `background` of VkrShadeArgs,

@@ -20,6 +20,7 @@ ENV_LAYOUT_LINEAR, ENV_LAYOUT_TILED_4X4 = 0, 1
 WRAP_REPEAT, WRAP_CLAMP = 0, 1
 SRC_RGBA8_SRGB, SRC_RGBA16F = 0, 1
 POST_SRGB_TARGET = 1
+GBUFFER_STATIC_MAX_PIXELS, GBUFFER_STATIC_MAX_DRAWS = 2097152, 64
 IRRADIANCE_SEQUENTIAL, IRRADIANCE_PHI_SLICES = 0, 1
 (TARGET_COLOR, TARGET_THRESHOLD, TARGET_BLOOM1, TARGET_BLOOM2, TARGET_LDR,
  TARGET_ENV, TARGET_IRRADIANCE, TARGET_PREFILTER, TARGET_BRDF_LUT) = range(9)
@@ -138,6 +139,7 @@ PROTOTYPES = {
     "vkr_light_coverage": [C.POINTER(CoverageArgs), _vp],
     "vkr_point_shadow_maps": [C.POINTER(PointShadowArgs), _vp],
     "vkr_gbuffer": [C.POINTER(GpassArgs), _vp],
+    "vkr_gbuffer_static": [C.POINTER(GpassArgs), _vp],
     "vkr_skybox": [_vp, _i32, _i32, C.POINTER(SceneInfo), _i32, _i32, _i32, _i32, _vp, _vp],
     "vkr_gbuffer_workspace_bytes": [_i32, _i32, _i32],
     "vkr_dir_shadow_map": [C.POINTER(DirShadowArgs), _vp],

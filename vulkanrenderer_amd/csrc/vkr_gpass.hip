@@ -232,32 +232,35 @@ extern "C" int64_t vkr_gbuffer_workspace_bytes(int32_t width, int32_t rows, int3
     return (int64_t)width * rows * 8 + (int64_t)n_draws * (int64_t)sizeof(VkrGpassDraw) + 256;
 }
 
-extern "C" int32_t vkr_gbuffer(const VkrGpassArgs *a, void *stream)
+namespace vkr {
+
+// Checks everything about a geometry-pass call except where its scratch memory comes from.
+static int32_t check_gbuffer(const char *who, const VkrGpassArgs *a)
 {
-    using namespace vkr;
-    VKR_REQUIRE(a != nullptr, "vkr_gbuffer: args is null");
-    VKR_REQUIRE(a->width > 0 && a->rows > 0, "vkr_gbuffer: bad size %dx%d", a->width, a->rows);
-    VKR_REQUIRE(a->frame_rows >= a->rows && a->row0 >= 0 && a->row0 + a->rows <= a->frame_rows, "vkr_gbuffer: rows [%d,%d) outside a frame of %d rows", a->row0, a->row0 + a->rows, a->frame_rows);
-    VKR_REQUIRE(a->n_draws >= 0 && (a->n_draws == 0 || a->draws), "vkr_gbuffer: draws missing");
-    VKR_REQUIRE(a->albedo && a->normal && a->arm && a->position, "vkr_gbuffer: an output image is null");
+    VKR_REQUIRE(a != nullptr, "%s: args is null", who);
+    VKR_REQUIRE(a->width > 0 && a->rows > 0, "%s: bad size %dx%d", who, a->width, a->rows);
+    VKR_REQUIRE(a->frame_rows >= a->rows && a->row0 >= 0 && a->row0 + a->rows <= a->frame_rows, "%s: rows [%d,%d) outside a frame of %d rows", who, a->row0, a->row0 + a->rows, a->frame_rows);
+    VKR_REQUIRE(a->n_draws >= 0 && (a->n_draws == 0 || a->draws), "%s: draws missing", who);
+    VKR_REQUIRE(a->albedo && a->normal && a->arm && a->position, "%s: an output image is null", who);
     uint64_t total_tris = 0;
     for (int d = 0; d < a->n_draws; d++) {
         const VkrGpassDraw &g = a->draws[d];
-        VKR_REQUIRE(g.positions && g.texcoords && g.normals && g.tangents && g.indices && g.n_verts > 0 && g.n_tris >= 0, "vkr_gbuffer: draw %d has no mesh", d);
+        VKR_REQUIRE(g.positions && g.texcoords && g.normals && g.tangents && g.indices && g.n_verts > 0 && g.n_tris >= 0, "%s: draw %d has no mesh", who, d);
         const VkrTexture *tex[3] = {&g.albedo, &g.normal, &g.arm};
-        for (const VkrTexture *t : tex) VKR_REQUIRE(t->rgba8 && t->width > 0 && t->height > 0, "vkr_gbuffer: draw %d lacks a material image", d);
+        for (const VkrTexture *t : tex) VKR_REQUIRE(t->rgba8 && t->width > 0 && t->height > 0, "%s: draw %d lacks a material image", who, d);
         total_tris += (uint64_t)g.n_tris;
     }
-    VKR_REQUIRE(total_tris < (1ull << 32) - 1, "vkr_gbuffer: too many triangles");
-    const int64_t need = vkr_gbuffer_workspace_bytes(a->width, a->rows, a->n_draws);
-    VKR_REQUIRE(a->workspace && a->workspace_bytes >= need, "vkr_gbuffer: workspace of %lld bytes needed (vkr_gbuffer_workspace_bytes)", (long long)need);
-    int32_t rc = ensure_srgb_table();
-    if (rc != VKR_OK) return rc;
+    VKR_REQUIRE(total_tris < (1ull << 32) - 1, "%s: too many triangles", who);
+    return VKR_OK;
+}
 
+// The launches of the geometry pass.  `vis` (one 64-bit key per pixel) and `dev_draws` (room for the draw
+// records) are device scratch memory; every key is reset here, so the scratch may hold anything on entry.
+static int32_t launch_gbuffer(const char *who, const VkrGpassArgs *a, unsigned long long *vis, VkrGpassDraw *dev_draws, void *stream)
+{
     GpassParams p;
     const size_t npx = (size_t)a->width * a->rows;
-    p.vis = (unsigned long long *)a->workspace;
-    VkrGpassDraw *dev_draws = (VkrGpassDraw *)((char *)a->workspace + ((npx * 8 + 255) & ~(size_t)255));
+    p.vis = vis;
     p.draws = dev_draws; p.n_draws = a->n_draws;
     if (a->n_draws) VKR_HIP_CHECK(hipMemcpyAsync(dev_draws, a->draws, (size_t)a->n_draws * sizeof(VkrGpassDraw), hipMemcpyHostToDevice, as_stream(stream)));
     // (proj * view), as gpass.vert:26 associates it
@@ -279,7 +282,63 @@ extern "C" int32_t vkr_gbuffer(const VkrGpassArgs *a, void *stream)
         base += (unsigned)a->draws[d].n_tris;
     }
     hipLaunchKernelGGL(gpass_resolve_kernel, dim3((unsigned)((a->width + 63) / 64), (unsigned)((a->rows + 3) / 4)), dim3(256), 0, as_stream(stream), p);
-    return launch_status("vkr_gbuffer");
+    return launch_status(who);
+}
+
+// Scratch memory of vkr_gbuffer_static: the visibility keys followed by the draw records, resident in every
+// device's copy of the code object from the moment the library is loaded (16 MiB + 16 KiB per GPU).
+static constexpr size_t GPS_KEY_BYTES = (size_t)VKR_GBUFFER_STATIC_MAX_PIXELS * 8;
+static constexpr size_t GPS_DRAW_BYTES = ((size_t)VKR_GBUFFER_STATIC_MAX_DRAWS * sizeof(VkrGpassDraw) + 255) & ~(size_t)255;
+static __device__ __align__(256) unsigned char scratch[GPS_KEY_BYTES + GPS_DRAW_BYTES];
+static void *g_scratch_ptr[64];  // per device ordinal: the device address of that GPU's copy of `scratch`
+
+// The device address of the current device's `scratch`, looked up once per device.  (In host code the
+// array's name is only a handle for the symbol; kernels and copies must be given this address.)
+static int32_t static_scratch(void **out)
+{
+    int dev = 0;
+    VKR_HIP_CHECK(hipGetDevice(&dev));
+    VKR_REQUIRE(dev >= 0 && dev < 64, "device ordinal %d out of range", dev);
+    std::lock_guard<std::mutex> lock(g_gp_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void *ptr = nullptr;
+        VKR_HIP_CHECK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        VKR_REQUIRE(ptr != nullptr, "hipGetSymbolAddress returned a null address for the scratch array");
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return VKR_OK;
+}
+
+}  // namespace vkr
+
+extern "C" int32_t vkr_gbuffer(const VkrGpassArgs *a, void *stream)
+{
+    using namespace vkr;
+    int32_t rc = check_gbuffer("vkr_gbuffer", a);
+    if (rc != VKR_OK) return rc;
+    const int64_t need = vkr_gbuffer_workspace_bytes(a->width, a->rows, a->n_draws);
+    VKR_REQUIRE(a->workspace && a->workspace_bytes >= need, "vkr_gbuffer: workspace of %lld bytes needed (vkr_gbuffer_workspace_bytes)", (long long)need);
+    if ((rc = ensure_srgb_table()) != VKR_OK) return rc;
+    const size_t npx = (size_t)a->width * a->rows;
+    VkrGpassDraw *dev_draws = (VkrGpassDraw *)((char *)a->workspace + ((npx * 8 + 255) & ~(size_t)255));
+    return launch_gbuffer("vkr_gbuffer", a, (unsigned long long *)a->workspace, dev_draws, stream);
+}
+
+extern "C" int32_t vkr_gbuffer_static(const VkrGpassArgs *a, void *stream)
+{
+    using namespace vkr;
+    int32_t rc = check_gbuffer("vkr_gbuffer_static", a);
+    if (rc != VKR_OK) return rc;
+    VKR_REQUIRE((int64_t)a->width * a->rows <= (int64_t)VKR_GBUFFER_STATIC_MAX_PIXELS,
+                "vkr_gbuffer_static: %dx%d = %lld pixels exceed the fixed scratch of %d pixels; use vkr_gbuffer with a workspace",
+                a->width, a->rows, (long long)a->width * a->rows, VKR_GBUFFER_STATIC_MAX_PIXELS);
+    VKR_REQUIRE(a->n_draws <= VKR_GBUFFER_STATIC_MAX_DRAWS, "vkr_gbuffer_static: %d draws exceed the fixed scratch of %d draws; use vkr_gbuffer with a workspace",
+                a->n_draws, VKR_GBUFFER_STATIC_MAX_DRAWS);
+    if ((rc = ensure_srgb_table()) != VKR_OK) return rc;
+    void *base = nullptr;
+    if ((rc = static_scratch(&base)) != VKR_OK) return rc;
+    return launch_gbuffer("vkr_gbuffer_static", a, (unsigned long long *)base, (VkrGpassDraw *)((char *)base + GPS_KEY_BYTES), stream);
 }
 
 extern "C" int32_t vkr_skybox(const void *env, int32_t env_n, int32_t env_layout, const VkrSceneInfo *scene,
