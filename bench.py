@@ -3,18 +3,30 @@ shadowed point lights (the headline configuration: 3840x2160, 64 point lights wi
 maps + a 4096^2 directional PCF shadow map), plus the IBL precompute time.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 8                      # starts its own 8 ranks (one process per GPU, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One step = one frame through composition -> bloom 1 -> (halo exchange) -> bloom 2 + post-process on
-inputs already resident in HBM.  With N > 1 every rank owns a 3840x2160 strip of a 3840 x (2160 N)
-frame (weak scaling); strips swap 4 bloom rows with their neighbours over RCCL and the RGBA8 strips
-are gathered on rank 0 inside the timed region.  Rank 0 prints one JSON line.
+inputs already resident in HBM.  With N > 1 the SAME 3840x2160 frame is cut into N horizontal strips
+(strong scaling): every rank shades and blurs its strip, swaps 4 bloom rows with its neighbours over
+RCCL, and the RGBA8 strips are gathered on rank 0 inside the timed region; rank 0 then renders the
+whole frame alone and checks the gathered image against it byte for byte.  Two further N > 1 shapes are
+reported as extra keys: a full 3840x2160 strip per rank (weak scaling) and a 16384x2048 strip with 256
+lights per rank (the 16384^2 / 8-GPU configuration).  Rank 0 prints one JSON line.
+
+Started without WORLD_SIZE in the environment and with --gpus N > 1, the script starts N child
+processes of itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set) before anything
+touches a GPU, and exits with their status.  VKR_DIST_BACKEND=gloo is a rehearsal switch for machines
+with fewer GPUs than ranks (ranks then share devices; RCCL refuses two ranks on one device);
+--transport-only rehearses the launcher, the halo exchange and the gather on a machine without any GPU.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,16 +37,136 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 WIDTH, HEIGHT, LIGHTS, CUBE_RES, DIR_RES = 3840, 2160, 64, 1024, 4096
+C5_WIDTH, C5_ROWS, C5_LIGHTS = 16384, 2048, 256  # per-GPU share of the 16384^2 / 256-light / 8-GPU configuration
 SEED = 0x5EED0003
 PEAK_FP32_TFLOPS = 157.3   # MI355X FP32 vector peak
 PEAK_HBM_GBS = 8000.0      # MI355X HBM3E peak
 OPS_PER_PIXEL = 504        # canonical FP32 ops per pixel outside the light loop
 OPS_PER_PIXEL_LIGHT = 810  # canonical FP32 ops per (pixel, light) pair
+# canonical FP32 ops per IBL sample / texel (the same counting convention as the two figures above)
+OPS_IRRADIANCE_SAMPLE, OPS_PREFILTER_SAMPLE, OPS_BRDF_SAMPLE, OPS_EQUIRECT_TEXEL = 72, 110, 60, 80
+IRRADIANCE_SAMPLES, GGX_SAMPLES = 252 * 63, 1024
 
 
-def build_inputs(rank: int, device, rows: int, n_lights: int, cube_res: int, dir_res: int):
-    """Replicated scene data from SEED, this rank's G-buffer strip from SEED + 1000 + rank; IBL images
-    computed on the GPU by the library from a synthetic environment (reference sizes 512/32/128/512)."""
+# ---------------------------------------------------------------------------------------------
+# launcher: one child process per rank, started before any GPU call
+# ---------------------------------------------------------------------------------------------
+
+def launch_ranks(n: int, timeout_s: float) -> int:
+    """Starts `n` copies of this command as ranks 0..n-1 and waits for them.  Rank 0 inherits stdout
+    (the JSON line); all inherit stderr.  If a rank fails or the time limit passes, the others are
+    terminated (by their process ids) and the status is non-zero."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if rank == 0 else subprocess.DEVNULL))
+    deadline = time.monotonic() + timeout_s
+    status = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            rc = p.poll()
+            if rc is not None:
+                live.remove(p)
+                if rc != 0 and status == 0:
+                    status = rc if rc > 0 else 1
+        if status != 0 or time.monotonic() > deadline:
+            if not status:
+                status = 124
+                print(f"bench.py: ranks still running after {timeout_s:.0f} s; stopping them", file=sys.stderr)
+            for p in live:
+                p.terminate()
+            for p in live:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    return status
+
+
+# ---------------------------------------------------------------------------------------------
+# transport rehearsal without a GPU
+# ---------------------------------------------------------------------------------------------
+
+class PatternBackend:
+    """Stand-in for the HIP passes on CPU tensors, for --transport-only: every pass writes bytes that
+    depend on the frame row and, for the last pass, on the 4 rows above and below, so that the gathered
+    image is right only if the strip split, both halo directions, the clamp ranges and the gather are.
+    No kernel runs and nothing is timed as throughput."""
+
+    def empty(self, shape, dtype):
+        import torch
+        return torch.zeros(shape, dtype=dtype)
+
+    def shade(self, frame, color, thr, y0=0, y1=None):
+        import torch
+        y1 = frame.rows if y1 is None else y1
+        g = torch.arange(frame.row0 + y0, frame.row0 + y1, dtype=torch.float32)
+        thr[y0:y1] = ((g * 7) % 61)[:, None, None].to(torch.float16)
+        color[y0:y1] = ((g * 3) % 17)[:, None, None].to(torch.float16)
+
+    def bloom_h(self, thr, bloom1, rows, y0=0, y1=None):
+        from vulkanrenderer_amd.strips import HALO
+        y1 = rows if y1 is None else y1
+        bloom1[HALO + y0:HALO + y1] = thr[y0:y1]
+
+    def bloomv_post(self, bloom1, hdr, out, lo, hi, row0=0):
+        import torch
+        from vulkanrenderer_amd.strips import HALO
+        rows = hdr.shape[0]
+        idx = (torch.arange(rows)[:, None] + HALO + row0 + torch.arange(-4, 5)[None, :]).clamp(lo, hi)
+        s = bloom1.float()[idx].sum(1) + hdr.float()
+        out[...] = (s % 256).to(torch.uint8)
+
+
+def run_transport_only(args, rank: int, world: int) -> None:
+    import types
+    import torch
+    import torch.distributed as dist
+    from vulkanrenderer_amd.strips import StripPlan, StripRenderer
+
+    if world > 1:
+        dist.init_process_group("gloo")
+    w, h = min(args.width, 64), min(args.height, 97)
+    plan = StripPlan.make(rank, world, h)
+    r = StripRenderer(plan, w, backend=PatternBackend(), frames_in_flight=2 if world > 1 else 1)
+    frame = types.SimpleNamespace(rows=plan.rows, row0=plan.row0, width=w)
+    parts = None
+    for _ in range(args.warmup + args.steps):
+        r.render(frame)
+        parts = r.gather(0)
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        whole = StripRenderer(StripPlan.make(0, 1, h), w, backend=PatternBackend())
+        want = whole.render(types.SimpleNamespace(rows=h, row0=0, width=w))
+        same = bool(torch.equal(torch.cat(parts, 0), want))
+        print(json.dumps({"metric": "Mpixels/s deferred PBR+bloom+ACES @4K 64 shadowed lights", "value": None, "unit": "Mpixels/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "transport_only": True,
+                          "data": "none: rehearsal of the launcher, halo exchange and gather on CPU tensors; no kernel ran",
+                          "distributed": {"backend": "gloo", "world": world}, "frame": f"{w}x{h}",
+                          "gathered_equals_single_rank": same}), flush=True)
+        if not same:
+            raise SystemExit("transport rehearsal: the gathered image differs from the single-rank image")
+    if world > 1:
+        dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------
+# inputs
+# ---------------------------------------------------------------------------------------------
+
+def build_scene(device, n_lights: int, cube_res: int, dir_res: int):
+    """Replicated scene data from SEED: lights, shadow maps (cubes re-laid into the library's tiled layout on the
+    device), and IBL images computed on the GPU by the library from a synthetic environment (reference
+    sizes 512 / 32 / 128 / 512).  Returns the host-side record and a DeviceFrame without a G-buffer."""
     import torch
     from vulkanrenderer_amd import _lib, passes as P, synth
 
@@ -50,11 +182,107 @@ def build_inputs(rank: int, device, rows: int, n_lights: int, cube_res: int, dir
     P.prefilter(env, pre, 0.0)
     P.brdf_lut(lut)
     torch.cuda.synchronize()
-    albedo, normal, arm, position = synth.make_gbuffer(np.random.default_rng(SEED + 1000 + rank), WIDTH, rows)
-    f = synth.FrameInputs(WIDTH, rows, albedo, normal, arm, position, synth.default_scene_info(), lights,
-                          dir_shadow, cube_shadow, P.f16_bits(irr), P.f16_bits(pre), P.f16_bits(lut))
-    # the point-shadow cubes are resident in the library's tiled layout (DeviceFrame.upload re-lays them once)
-    return f, P.DeviceFrame.upload(f, device)
+    return dict(lights=lights, dir_shadow=dir_shadow, cube_shadow=cube_shadow, scene=synth.default_scene_info(),
+                irradiance=P.f16_bits(irr), prefilter=P.f16_bits(pre), brdf_lut=P.f16_bits(lut))
+
+
+def frame_of(scene: dict, gbuffer, width: int, rows: int):
+    from vulkanrenderer_amd import synth
+    albedo, normal, arm, position = gbuffer
+    return synth.FrameInputs(width, rows, albedo, normal, arm, position, scene["scene"], scene["lights"], scene["dir_shadow"],
+                             scene["cube_shadow"], scene["irradiance"], scene["prefilter"], scene["brdf_lut"])
+
+
+def strip_device_frame(whole_dev, f_rows, row0: int, rows: int, device):
+    """A DeviceFrame for rows [row0, row0 + rows) of a frame whose scene data is already on the device."""
+    import dataclasses
+    from vulkanrenderer_amd import passes as P
+    return dataclasses.replace(whole_dev, rows=rows,
+                               albedo=P.to_device_f16(f_rows.albedo, device), normal=P.to_device_f16(f_rows.normal, device),
+                               arm=P.to_device_f16(f_rows.arm, device), position=P.to_device_f16(f_rows.position, device))
+
+
+# ---------------------------------------------------------------------------------------------
+# timed loops
+# ---------------------------------------------------------------------------------------------
+
+def timed_frames(renderer, dev_frame, world: int, steps: int, warmup: int, device) -> float:
+    """`warmup` untimed frames, then exactly `steps` frames between barrier + synchronize; seconds, max over ranks."""
+    import torch
+    import torch.distributed as dist
+
+    def step():
+        renderer.render(dev_frame)
+        if world > 1:
+            renderer.gather(0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def phase_times(renderer, dev_frame, world: int, steps: int, device) -> dict:
+    """Milliseconds per frame of the phases of StripRenderer.render / gather (HIP events on the streams the work
+    runs on; mean over `steps` frames, max over ranks).  halo_wait is what of the exchange the interior work did
+    not hide; gather is the RGBA8 transfer to rank 0 (on the side stream: it overlaps the next frame)."""
+    import torch
+    import torch.distributed as dist
+    names = ["edge_bands_shade_bloomh", "interior_shade_bloomh", "interior_bloomv_post", "halo_wait", "edge_bloomv_post", "gather"]
+    acc = {n: 0.0 for n in names}
+    for _ in range(steps):
+        renderer.marks = []
+        renderer.render(dev_frame)
+        if world > 1:
+            renderer.gather(0)
+        torch.cuda.synchronize()
+        ev = dict(renderer.marks)
+        order = ["frame_start"] + names[:5]
+        for a, b in zip(order, order[1:]):
+            acc[b] += ev[a].elapsed_time(ev[b])
+        if "gather" in ev:
+            acc["gather"] += ev["gather_start"].elapsed_time(ev["gather"])
+    renderer.marks = None
+    t = torch.tensor([acc[n] / steps for n in names], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return {n: round(float(v), 4) for n, v in zip(names, t.tolist())}
+
+
+def kernel_times(renderer, dev_frame, rows: int, steps: int) -> dict:
+    """Average duration of the three kernels of a step, each between two HIP events on the launch stream."""
+    import torch
+    names = ["shade", "bloom_h", "bloomv_post"]
+    acc = {n: 0.0 for n in names}
+    be = renderer.backend
+    lo, hi = 4, 4 + rows - 1
+    for _ in range(steps):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
+        be.shade(dev_frame, renderer.color, renderer.threshold)
+        ev[1].record()
+        be.bloom_h(renderer.threshold, renderer.bloom1, rows)
+        ev[2].record()
+        be.bloomv_post(renderer.bloom1, renderer.color, renderer.ldr, lo, hi)
+        ev[3].record()
+        torch.cuda.synchronize()
+        for i, n in enumerate(names):
+            acc[n] += ev[i].elapsed_time(ev[i + 1])
+    return {n: acc[n] / steps for n in names}
 
 
 def time_shadow_retile(f, device, reps: int = 5) -> dict:
@@ -76,9 +304,10 @@ def time_shadow_retile(f, device, reps: int = 5) -> dict:
             "bytes": 2 * lin.numel() * 4}
 
 
-def time_ibl(device) -> dict:
+def time_ibl(device, reps: int = 3) -> tuple[dict, list]:
     """IBL precompute at the BASELINE configuration: 4096x2048 HDR equirect -> 2048^2 cube ->
-    irradiance 64^2, 5-mip GGX prefilter (128^2 .. 8^2, 1024 samples) and 512^2 BRDF LUT."""
+    irradiance 64^2, 5-mip GGX prefilter (128^2 .. 8^2, 1024 samples) and 512^2 BRDF LUT.  Returns the
+    per-stage milliseconds and one roofline record per kernel (average of `reps` launches, HIP events)."""
     import torch
     from vulkanrenderer_amd import _lib, passes as P, synth
 
@@ -88,29 +317,64 @@ def time_ibl(device) -> dict:
     irr = torch.empty((6, 64, 64, 4), dtype=torch.float16, device=device)
     pres = [torch.empty((6, 128 >> m, 128 >> m, 4), dtype=torch.float16, device=device) for m in range(5)]
     lut = torch.empty((512, 512, 2), dtype=torch.float16, device=device)
+    tiled_box = [None]
 
     def run():
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(10)]
         ev[0].record()
         P.equirect_to_cube(src, _lib.SRC_RGBA16F, env)
-        tiled = P.tile_env_cube(env)  # the copy the two sampling passes read; counted with the equirect stage
         ev[1].record()
-        P.irradiance(tiled, irr, _lib.IRRADIANCE_SEQUENTIAL, env_layout=_lib.ENV_LAYOUT_TILED_4X4)
+        tiled = tiled_box[0] = P.tile_env_cube(env)  # the copy the two sampling passes read; counted with the equirect stage
         ev[2].record()
+        P.irradiance(tiled, irr, _lib.IRRADIANCE_SEQUENTIAL, env_layout=_lib.ENV_LAYOUT_TILED_4X4)
+        ev[3].record()
         for m in range(5):
             P.prefilter(tiled, pres[m], m / 4.0, env_layout=_lib.ENV_LAYOUT_TILED_4X4)
-        ev[3].record()
+            ev[4 + m].record()
         P.brdf_lut(lut)
-        ev[4].record()
+        ev[9].record()
         torch.cuda.synchronize()
-        return [ev[i].elapsed_time(ev[i + 1]) for i in range(4)]
+        return [ev[i].elapsed_time(ev[i + 1]) for i in range(9)]
 
     run()
-    t = run()
-    return {"equirect_ms": round(t[0], 3), "irradiance_ms": round(t[1], 3), "prefilter_ms": round(t[2], 3),
-            "brdf_lut_ms": round(t[3], 3), "total_ms": round(sum(t), 3),
-            "config": "equirect 4096x2048 RGBA16F -> env 2048^2 (+ 4x4-tiled copy), irradiance 64^2 in the shader's summation order, "
-                      "prefilter 128^2 x5 mips, LUT 512^2"}
+    t = np.mean([run() for _ in range(reps)], axis=0)
+    eq, tile, irr_ms, pre_ms, lut_ms = t[0], t[1], t[2], t[3:8], t[8]
+    stages = {"equirect_ms": round(float(eq + tile), 3), "irradiance_ms": round(float(irr_ms), 3), "prefilter_ms": round(float(pre_ms.sum()), 3),
+              "brdf_lut_ms": round(float(lut_ms), 3), "total_ms": round(float(t.sum()), 3),
+              "config": "equirect 4096x2048 RGBA16F -> env 2048^2 (+ 4x4-tiled copy), irradiance 64^2 in the shader's summation order, "
+                        "prefilter 128^2 x5 mips, LUT 512^2"}
+
+    def valu(kernel, ops, ms, algorithmic, **more):
+        tf = ops / (ms * 1e-3) / 1e12
+        return dict(kernel=kernel, bound="valu", algorithmic=algorithmic, achieved=round(tf, 3), peak=PEAK_FP32_TFLOPS, unit="TFLOP/s",
+                    frac=round(tf / PEAK_FP32_TFLOPS, 4), avg_launch_ms=round(float(ms), 4), **more)
+
+    def hbm(kernel, nbytes, ms, algorithmic):
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        return dict(kernel=kernel, bound="hbm", algorithmic=algorithmic, achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                    frac=round(gbs / PEAK_HBM_GBS, 4), avg_launch_ms=round(float(ms), 4))
+
+    irr_texels, lut_texels = 6 * 64 * 64, 512 * 512
+    env_bytes, src_bytes = env.numel() * 2, src.numel() * 2
+    # every irradiance sample gathers the 2x2 footprint of a bilinear lookup (4 texels x 8 B) from the 201 MB cube
+    gather_bytes = irr_texels * IRRADIANCE_SAMPLES * 32
+    roof = [
+        hbm("equirect_kernel", env_bytes + src_bytes, eq, f"{env_bytes} B written (8 B/texel) + {src_bytes} B source read once"),
+        hbm("tile_rgba16f_kernel", 2 * env_bytes, tile, f"{env_bytes} B read + {env_bytes} B written"),
+        valu("irradiance_texel_kernel", OPS_IRRADIANCE_SAMPLE * IRRADIANCE_SAMPLES * irr_texels, irr_ms,
+             f"{OPS_IRRADIANCE_SAMPLE} FP32 ops x {IRRADIANCE_SAMPLES} samples x {irr_texels} texels",
+             gather={"bytes": gather_bytes, "GB/s": round(gather_bytes / (irr_ms * 1e-3) / 1e9, 1),
+                     "note": "32 B of texels per bilinear sample, served by L1/L2/Infinity Cache; the memory-side line traffic is in profiles/"}),
+    ]
+    for m in range(5):
+        n = 128 >> m
+        roof.append(valu(f"prefilter_texel_kernel mip {m} (roughness {m / 4:g})", OPS_PREFILTER_SAMPLE * GGX_SAMPLES * 6 * n * n, pre_ms[m],
+                         f"{OPS_PREFILTER_SAMPLE} FP32 ops x {GGX_SAMPLES} samples x {6 * n * n} texels"))
+    roof.append(valu("prefilter_texel_kernel, 5 mips", OPS_PREFILTER_SAMPLE * GGX_SAMPLES * sum(6 * (128 >> m) ** 2 for m in range(5)), pre_ms.sum(),
+                     f"{OPS_PREFILTER_SAMPLE} FP32 ops x {GGX_SAMPLES} samples x 130944 texels, five launches"))
+    roof.append(valu("brdf_lut_kernel", OPS_BRDF_SAMPLE * GGX_SAMPLES * lut_texels, lut_ms,
+                     f"{OPS_BRDF_SAMPLE} FP32 ops x {GGX_SAMPLES} samples x {lut_texels} texels"))
+    return stages, roof
 
 
 def time_coverage(f, dev_frame, renderer, device) -> dict:
@@ -196,20 +460,23 @@ def time_shadow_pass(f, dev_frame, device) -> dict:
             "config": f"{nl} lights x 6 x {res}^2 D32F (written as 8x4 tiles) + {dres}^2 directional map; mesh {len(verts)} vertices, {len(tris)} triangles"}
 
 
-def measured_traffic(lights: int, cube_res: int, dir_res: int) -> dict:
-    """HBM-side bytes per launch from the committed rocprofv3 counter passes (profiles/r1_traffic.json);
-    counters cannot be read from inside this process, so the figures apply only to the workload they
-    were collected on and are dropped (null) for any other."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_traffic.json")
+COUNTER_FILE = os.path.join("profiles", "r2_counters.json")
+
+
+def measured_counters(width: int, rows: int, lights: int, cube_res: int, dir_res: int) -> dict:
+    """Per-launch hardware-counter figures from the committed rocprofv3 --pmc passes of this command
+    (profiles/r2_counters.json): HBM-side bytes, vector instructions, gather instructions.  Counters cannot
+    be read from inside this process, so the figures apply only to the workload they were collected on and
+    are dropped for any other."""
     try:
-        with open(path) as fh:
+        with open(os.path.join(ROOT, COUNTER_FILE)) as fh:
             rec = json.load(fh)
     except OSError:
         return {}
     w = rec.get("workload", {})
-    if (w.get("width"), w.get("rows"), w.get("lights"), w.get("cube_res"), w.get("dir_res")) != (WIDTH, HEIGHT, lights, cube_res, dir_res):
+    if (w.get("width"), w.get("rows"), w.get("lights"), w.get("cube_res"), w.get("dir_res")) != (width, rows, lights, cube_res, dir_res):
         return {}
-    return {k: v["traffic_bytes"] for k, v in rec.get("kernels", {}).items()}
+    return rec.get("kernels", {})
 
 
 def cpu_baseline(f, gpu_color, gpu_thr, sample_rows: int) -> dict:
@@ -230,94 +497,144 @@ def cpu_baseline(f, gpu_color, gpu_thr, sample_rows: int) -> dict:
             "gpu_rows_bit_exact": exact}
 
 
+def extra_shapes(args, rank: int, world: int, device, scene: dict, scene_dev) -> dict:
+    """The two other N > 1 shapes: a full-size strip per rank (weak scaling) and the per-GPU share of the
+    16384^2 / 256-light frame.  Inputs are synthetic repeats: timing only, the parity of these shapes is the
+    test suite's business."""
+    import dataclasses
+    import torch
+    from vulkanrenderer_amd import passes as P, synth
+    from vulkanrenderer_amd.strips import StripPlan, StripRenderer
+    out = {}
+    steps, warmup = max(args.steps // 2, 3), 2
+
+    # (a) weak: every rank owns a WIDTH x HEIGHT strip of a WIDTH x (HEIGHT * world) frame
+    g = synth.make_gbuffer(np.random.default_rng(SEED + 1000 + rank), WIDTH, HEIGHT)
+    f = frame_of(scene, g, WIDTH, HEIGHT)
+    dev_frame = strip_device_frame(scene_dev, f, 0, HEIGHT, device)
+    r = StripRenderer(StripPlan.make(rank, world, HEIGHT * world), WIDTH, device=device, frames_in_flight=2)
+    t = timed_frames(r, dev_frame, world, steps, warmup, device)
+    out["weak_full_strip_per_rank"] = {"frame": f"{WIDTH}x{HEIGHT * world}", "strip": f"{WIDTH}x{HEIGHT}", "lights": args.lights, "scaling": "weak",
+                                       "ms_per_step": round(t / steps * 1e3, 4), "Mpixels/s": round(WIDTH * HEIGHT * world / (t / steps) / 1e6, 1),
+                                       "phases_ms": phase_times(r, dev_frame, world, steps, device)}
+    del r, dev_frame, f, g
+    torch.cuda.empty_cache()
+
+    # (b) the 16384^2 / 256-light configuration: 16384 x 2048 rows per rank, 256 lights with 1024^2 cubes
+    reps = C5_LIGHTS // args.lights
+    if reps >= 1 and C5_LIGHTS % args.lights == 0:
+        g = synth.make_gbuffer(np.random.default_rng(SEED + 2000 + rank), 4096, C5_ROWS)
+        wide = [np.ascontiguousarray(np.tile(a, (1, C5_WIDTH // 4096, 1))) for a in g]
+        lights = np.concatenate([scene["lights"]] * reps)
+        dev_lights = torch.from_numpy(np.frombuffer(lights.tobytes(), dtype=np.uint8).copy()).to(device)
+        cubes = scene_dev.cube_shadow.repeat(reps, 1, 1, 1)
+        base = dataclasses.replace(scene_dev, width=C5_WIDTH, lights=dev_lights, n_lights=C5_LIGHTS, cube_shadow=cubes)
+        f = synth.FrameInputs(C5_WIDTH, C5_ROWS, *wide, scene["scene"], lights, scene["dir_shadow"], scene["cube_shadow"],
+                              scene["irradiance"], scene["prefilter"], scene["brdf_lut"])
+        dev_frame = strip_device_frame(base, f, 0, C5_ROWS, device)
+        r = StripRenderer(StripPlan.make(rank, world, C5_ROWS * world), C5_WIDTH, device=device, frames_in_flight=2)
+        t = timed_frames(r, dev_frame, world, 3, 1, device)
+        out["c5_strip_per_rank"] = {"frame": f"{C5_WIDTH}x{C5_ROWS * world}", "strip": f"{C5_WIDTH}x{C5_ROWS}", "lights": C5_LIGHTS, "scaling": "weak",
+                                    "ms_per_step": round(t / 3 * 1e3, 3), "Mpixels/s": round(C5_WIDTH * C5_ROWS * world / (t / 3) / 1e6, 1),
+                                    "phases_ms": phase_times(r, dev_frame, world, 3, device),
+                                    "inputs": f"{C5_LIGHTS} lights = the {args.lights} synthetic lights and their {args.cube_res}^2 depth cubes repeated x{reps} "
+                                              f"({cubes.numel() * 4 / 2**30:.1f} GiB resident); G-buffer = a 4096-wide synthetic strip repeated x4"}
+        del r, dev_frame, f, wide, g, cubes, base
+        torch.cuda.empty_cache()
+    return out
+
+
 def main() -> None:
     global WIDTH, HEIGHT
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--width", type=int, default=WIDTH, help="strip width per GPU (default: the headline 3840)")
-    ap.add_argument("--height", type=int, default=HEIGHT, help="strip rows per GPU (default: the headline 2160)")
+    ap.add_argument("--width", type=int, default=WIDTH, help="frame width (default: the headline 3840)")
+    ap.add_argument("--height", type=int, default=HEIGHT, help="frame rows, split over the GPUs (default: the headline 2160)")
     ap.add_argument("--lights", type=int, default=LIGHTS)
     ap.add_argument("--cube-res", type=int, default=CUBE_RES)
     ap.add_argument("--dir-res", type=int, default=DIR_RES)
     ap.add_argument("--cpu-rows", type=int, default=None, help="rows of the frame the CPU baseline shades (default: all; 0 = skip)")
     ap.add_argument("--no-ibl", action="store_true", help="skip the IBL precompute timing")
     ap.add_argument("--no-coverage", action="store_true", help="skip the light-volume coverage and shadow-pass timings")
+    ap.add_argument("--no-extra", action="store_true", help="N > 1: skip the weak-scaling and 16384-wide extra shapes")
+    ap.add_argument("--transport-only", action="store_true", help="rehearse launcher, halo exchange and gather on CPU tensors (no GPU, no kernels)")
+    ap.add_argument("--launch-timeout", type=float, default=900.0, help="seconds the self-started ranks may take")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+
+    # Self-launch: with --gpus N > 1 and no rank environment, start the N ranks as fresh child processes.
+    # Nothing has touched a GPU at this point (torch is not even imported), and the parent never does.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, args.launch_timeout))
+
     WIDTH, HEIGHT = args.width, args.height
-    args.cpu_rows = HEIGHT if args.cpu_rows is None else min(args.cpu_rows, HEIGHT)
-
-    import torch
-    import torch.distributed as dist
-    from vulkanrenderer_amd import _lib
-    from vulkanrenderer_amd.strips import StripPlan, StripRenderer
-
-    _lib.load()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    # One rank per GPU over RCCL.  VKR_DIST_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs
-    # than ranks (ranks then share devices; RCCL refuses two ranks on one device).
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.transport_only:
+        return run_transport_only(args, rank, world)
+
+    import torch
+    import torch.distributed as dist
+    from vulkanrenderer_amd import _lib, passes as P, synth
+    from vulkanrenderer_amd.strips import StripPlan, StripRenderer
+
+    _lib.load()
+    args.cpu_rows = HEIGHT if args.cpu_rows is None else min(args.cpu_rows, HEIGHT)
+    # One rank per GPU over RCCL.  VKR_DIST_BACKEND=gloo: rehearsal on a box with fewer GPUs than ranks.
     backend = os.environ.get("VKR_DIST_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    n_dev = max(torch.cuda.device_count(), 1)
+    if backend == "nccl" and world > n_dev:
+        raise SystemExit(f"{world} ranks over RCCL need {world} GPUs; {n_dev} visible (VKR_DIST_BACKEND=gloo rehearses on fewer)")
+    dev_index = local_rank if backend == "nccl" else local_rank % n_dev
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
 
-    f, dev_frame = build_inputs(rank, device, HEIGHT, args.lights, args.cube_res, args.dir_res)
-    plan = StripPlan.make(rank, world, HEIGHT * world)
+    # the frame: every rank builds the same scene and the same whole-frame G-buffer and keeps its own rows
+    scene = build_scene(device, args.lights, args.cube_res, args.dir_res)
+    whole = frame_of(scene, synth.make_gbuffer(np.random.default_rng(SEED + 1000), WIDTH, HEIGHT), WIDTH, HEIGHT)
+    plan = StripPlan.make(rank, world, HEIGHT)
+    f = whole.rows(plan.row0, plan.row0 + plan.rows)
+    dev_frame = P.DeviceFrame.upload(f, device)  # scene data + this rank's rows; cubes re-laid into tiles once
     # two frames in flight, like the reference (VulkanRenderer.cs:60): the gather of frame k overlaps frame k+1
     renderer = StripRenderer(plan, WIDTH, device=device, frames_in_flight=2 if world > 1 else 1)
 
-    def step():
-        renderer.render(dev_frame)
-        if world > 1:
-            renderer.gather(0)
+    elapsed = timed_frames(renderer, dev_frame, world, args.steps, args.warmup, device)
+    phases = phase_times(renderer, dev_frame, world, args.steps, device)
+    kernel_ms = kernel_times(renderer, dev_frame, plan.rows, args.steps)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # N > 1: the gathered image must be the single-GPU image, byte for byte
+    gathered_ok = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # per-kernel durations with HIP events on the launch stream (separate loop, same inputs)
-    names = ["shade", "bloom_h", "bloomv_post"]
-    acc = {n: 0.0 for n in names}
-    be = renderer.backend
-    lo, hi = (4, 4 + plan.rows - 1)
-    for _ in range(args.steps):
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        ev[0].record()
-        be.shade(dev_frame, renderer.color, renderer.threshold)
-        ev[1].record()
-        be.bloom_h(renderer.threshold, renderer.bloom1, plan.rows)
-        ev[2].record()
-        be.bloomv_post(renderer.bloom1, renderer.color, renderer.ldr, lo, hi)
-        ev[3].record()
+        renderer.render(dev_frame)
+        parts = renderer.gather(0)
         torch.cuda.synchronize()
-        for i, n in enumerate(names):
-            acc[n] += ev[i].elapsed_time(ev[i + 1])
-    kernel_ms = {n: acc[n] / args.steps for n in names}
-    barrier()
+        dist.barrier()
+        if rank == 0:
+            got = torch.cat(parts, 0)
+            alone = StripRenderer(StripPlan.make(0, 1, HEIGHT), WIDTH, device=device)
+            want = alone.render(strip_device_frame(dev_frame, whole, 0, HEIGHT, device))
+            gathered_ok = bool(torch.equal(got, want))
+            del alone, want, got
+        # leave the strip targets holding the strip's own frame for the checks below
+        renderer.render(dev_frame)
+        torch.cuda.synchronize()
+
+    extra = {}
+    if world > 1 and not args.no_extra:
+        extra = extra_shapes(args, rank, world, device, scene, dev_frame)
+        dist.barrier()
 
     if rank != 0:
         if world > 1:
@@ -325,38 +642,59 @@ def main() -> None:
         return
 
     px = WIDTH * HEIGHT
+    strip_px = WIDTH * plan.rows
     ms_per_step = elapsed / args.steps * 1e3
     # background texels (cleared G-buffer: ~10% of the synthetic frame) are discarded by the composition
     # shader and take nothing from the lights, so they are not counted as shading work
     shaded_px = int((f.normal.view(np.float16)[..., :3] != 0).any(axis=-1).sum())
     flops = (OPS_PER_PIXEL + OPS_PER_PIXEL_LIGHT * args.lights) * shaded_px
     shade_tflops = flops / (kernel_ms["shade"] * 1e-3) / 1e12
-    traffic = measured_traffic(args.lights, args.cube_res, args.dir_res)
+    ctr = measured_counters(WIDTH, plan.rows, args.lights, args.cube_res, args.dir_res)
+    shade_ctr = ctr.get("shade_kernel", {})
+    roofline = {"bound": "valu", "kernel": "shade_kernel", "achieved": round(shade_tflops, 3), "peak": PEAK_FP32_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(shade_tflops / PEAK_FP32_TFLOPS, 4), "traffic": shade_ctr.get("traffic_bytes"),
+                "traffic_source": f"{COUNTER_FILE}: separate rocprofv3 --pmc passes of this command, (2 x FETCH_SIZE + WRITE_SIZE) x 1024, not read in this run" if shade_ctr else None,
+                "algorithmic": f"({OPS_PER_PIXEL} + {OPS_PER_PIXEL_LIGHT} x {args.lights}) canonical FP32 ops x {shaded_px} shaded pixels per launch "
+                               f"({strip_px - shaded_px} background pixels of the {strip_px} do no shading work); a canonical-work rate: "
+                               "the kernel reaches the same bits in fewer issued instructions (see valu_lane_instructions) and skips lights "
+                               "that add exactly zero to a whole wave, so the fraction depends on the scene",
+                "avg_launch_ms": round(kernel_ms["shade"], 4)}
+    if shade_ctr:
+        roofline["valu_wave_instructions"] = shade_ctr.get("SQ_INSTS_VALU")
+        if shade_ctr.get("SQ_INSTS_VALU"):
+            roofline["valu_lane_instructions"] = shade_ctr["SQ_INSTS_VALU"] * 64
+            roofline["canonical_ops_per_lane_instruction"] = round(flops / (shade_ctr["SQ_INSTS_VALU"] * 64), 3)
+        roofline["wave_lights_without_taps_frac"] = shade_ctr.get("wave_lights_without_taps_frac")
+    post = [
+        {"bound": "hbm", "kernel": "bloom_h_kernel", "achieved": round(16 * strip_px / (kernel_ms["bloom_h"] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
+         "unit": "GB/s", "frac": round(16 * strip_px / (kernel_ms["bloom_h"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "avg_launch_ms": round(kernel_ms["bloom_h"], 4),
+         "algorithmic": "16 B/pixel", "traffic": ctr.get("bloom_h_kernel", {}).get("traffic_bytes")},
+        {"bound": "hbm", "kernel": "bloom_v_kernel<fused post>", "achieved": round(20 * strip_px / (kernel_ms["bloomv_post"] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
+         "unit": "GB/s", "frac": round(20 * strip_px / (kernel_ms["bloomv_post"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "avg_launch_ms": round(kernel_ms["bloomv_post"], 4),
+         "algorithmic": "20 B/pixel (8 bloom-1 + 8 colour in, 4 RGBA8 out)", "traffic": ctr.get("bloom_v_kernel", {}).get("traffic_bytes")}]
     out = {
         "metric": "Mpixels/s deferred PBR+bloom+ACES @4K 64 shadowed lights",
-        "value": round(px * world / (elapsed / args.steps) / 1e6, 3),
+        "value": round(px / (elapsed / args.steps) / 1e6, 3),
         "unit": "Mpixels/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{WIDTH}x{HEIGHT} strip per GPU ({WIDTH}x{HEIGHT * world} frame), {args.lights} point lights with "
-                               f"{args.cube_res}^2 cube shadow maps + {args.dir_res}^2 directional PCF shadow; composition + bloom x2 + ACES/gamma",
+        "config": {"workload": f"{WIDTH}x{HEIGHT} frame" + (f" cut into {world} strips of {plan.rows} rows, one per GPU" if world > 1 else "") +
+                               f", {args.lights} point lights with {args.cube_res}^2 cube shadow maps + {args.dir_res}^2 directional PCF shadow; "
+                               "composition + bloom x2 + ACES/gamma" + ("; halo exchange and RGBA8 gather on rank 0 inside the timed region" if world > 1 else ""),
                    "parallelism": f"strips{world}",
                    "storage": "RGBA16F G-buffer and targets, RGBA8 output, D32F shadow cubes in 8x4-texel tiles holding 25 x depth (the product light.frag forms per tap)"},
-        "roofline": {"bound": "valu", "kernel": "shade_kernel", "achieved": round(shade_tflops, 3), "peak": PEAK_FP32_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(shade_tflops / PEAK_FP32_TFLOPS, 4), "traffic": traffic.get("shade_kernel"),
-                     "algorithmic": f"({OPS_PER_PIXEL} + {OPS_PER_PIXEL_LIGHT} x {args.lights}) FP32 ops x {shaded_px} shaded pixels per launch "
-                                    f"({px - shaded_px} background pixels of the {px} do no shading work)",
-                     "avg_launch_ms": round(kernel_ms["shade"], 4)},
-        "roofline_post": [
-            {"bound": "hbm", "kernel": "bloom_h_kernel", "achieved": round(16 * px / (kernel_ms["bloom_h"] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
-             "unit": "GB/s", "frac": round(16 * px / (kernel_ms["bloom_h"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "avg_launch_ms": round(kernel_ms["bloom_h"], 4),
-             "algorithmic": "16 B/pixel", "traffic": traffic.get("bloom_h_kernel")},
-            {"bound": "hbm", "kernel": "bloom_v_kernel<fused post>", "achieved": round(20 * px / (kernel_ms["bloomv_post"] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
-             "unit": "GB/s", "frac": round(20 * px / (kernel_ms["bloomv_post"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "avg_launch_ms": round(kernel_ms["bloomv_post"], 4),
-             "algorithmic": "20 B/pixel (8 bloom-1 + 8 colour in, 4 RGBA8 out)", "traffic": traffic.get("bloom_v_kernel")}],
+        "distributed": {"backend": backend if world > 1 else None, "world": world,
+                        "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if world > 1 and backend == "nccl" else None,
+                        "devices": torch.cuda.device_count()},
+        "phases_ms": phases,
+        "roofline": roofline,
+        "roofline_post": post,
     }
+    if world > 1:
+        out["gathered_equals_single_gpu"] = gathered_ok
+        out.update(extra)
     if world == 1 and dev_frame.cube_layout != 0:
         rt = time_shadow_retile(f, device)
         rt["note"] = ("not part of a step: the shadow cubes are inputs resident in the tiled layout; "
@@ -369,20 +707,20 @@ def main() -> None:
         _lib.check(_lib.load().vkr_measure_peaks(ctypes.byref(fp32), ctypes.byref(copy)))
         out["measured_peaks"] = {"fp32_fma_loop_tflops": round(fp32.value, 1), "copy_1GiB_GBps": round(copy.value, 1),
                                  "shade_frac_of_measured": round(shade_tflops / fp32.value, 4),
-                                 "bloom_h_frac_of_measured": round(16 * px / (kernel_ms["bloom_h"] * 1e-3) / 1e9 / copy.value, 4),
-                                 "bloom_v_frac_of_measured": round(20 * px / (kernel_ms["bloomv_post"] * 1e-3) / 1e9 / copy.value, 4)}
+                                 "bloom_h_frac_of_measured": round(post[0]["achieved"] / copy.value, 4),
+                                 "bloom_v_frac_of_measured": round(post[1]["achieved"] / copy.value, 4)}
+        roofline["frac_of_measured"] = out["measured_peaks"]["shade_frac_of_measured"]
     if world == 1 and not args.no_coverage:
         out["light_volume_coverage"] = time_coverage(f, dev_frame, renderer, device)
         out["shadow_pass"] = time_shadow_pass(f, dev_frame, device)
         sp, cv = out["shadow_pass"], out["light_volume_coverage"]["reference_radii"]
-        whole = sp["point_shadow_ms"] + sp["dir_shadow_ms"] + sp["geometry_pass_ms"] + sp["skybox_ms"] + cv["coverage_ms"] + ms_per_step
-        out["frame_from_meshes"] = {"ms": round(whole, 3), "Mpixels/s": round(px / (whole * 1e-3) / 1e6, 1),
+        whole_ms = sp["point_shadow_ms"] + sp["dir_shadow_ms"] + sp["geometry_pass_ms"] + sp["skybox_ms"] + cv["coverage_ms"] + ms_per_step
+        out["frame_from_meshes"] = {"ms": round(whole_ms, 3), "Mpixels/s": round(px / (whole_ms * 1e-3) / 1e6, 1),
                                     "note": "shadow passes + geometry pass + skybox + light-volume coverage + the timed step: a frame in which "
                                             "every light moves and nothing but meshes, materials, lights and the camera is given"}
     if not args.no_ibl:
-        out["ibl_precompute"] = time_ibl(device)
+        out["ibl_precompute"], out["roofline_ibl"] = time_ibl(device)
     if world == 1 and args.cpu_rows > 0:
-        from vulkanrenderer_amd import passes as P
         out["cpu_baseline"] = cpu_baseline(f, P.f16_bits(renderer.color), P.f16_bits(renderer.threshold), args.cpu_rows)
     print(json.dumps(out), flush=True)
     if world > 1:

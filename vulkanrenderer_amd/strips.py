@@ -125,7 +125,8 @@ class StripRenderer:
         on_gpu = self.ldr.is_cuda
         self._side = torch.cuda.Stream(device=self.ldr.device) if on_gpu and len(self._ring) > 1 and plan.world > 1 else None
         self._slot_free = [None] * len(self._ring)  # per output strip: event "its last gather has finished"
-        self._gathered = None  # receive buffers of gather(), allocated on first use
+        self._gathered = [None] * len(self._ring)   # per output strip: rank dst's receive buffers, allocated on first use
+        self.marks = None  # a list: render() and gather() append (phase name, event recorded when the phase's work ends)
 
     def start_halo_exchange(self) -> list:
         """Rows HALO..2*HALO go to the rank above, the last HALO real rows to the rank below.
@@ -155,6 +156,12 @@ class StripRenderer:
             return self.render(self.backend.frame_from_draws(frame, draws, shadow_res, dir_res, p.total_rows, p.row0), volume_mesh)
         return self.render(self.backend.frame_from_draws(frame, draws, shadow_res, dir_res, p.total_rows, p.row0, env), volume_mesh)
 
+    def _mark(self, name: str, stream=None) -> None:
+        if self.marks is not None and self.ldr.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(stream if stream is not None else torch.cuda.current_stream())
+            self.marks.append((name, ev))
+
     def render(self, frame, volume_mesh=None) -> torch.Tensor:
         """composition and bloom 1 of the rows next to a neighbour -> halo exchange, overlapped with
         composition and bloom 1 of all other rows and the interior rows of bloom 2 + post-process ->
@@ -179,52 +186,64 @@ class StripRenderer:
         # halo exchange is in flight during the shading of everything else, the long part of a frame.
         a = 0 if p.is_top else min(8, r)
         b = r if p.is_bottom else max(((r - HALO) // 8) * 8, a)
+        self._mark("frame_start")
         for y0, y1 in ((0, a), (b, r)):
             if y1 > y0:
                 be.shade(frame, self.color, self.threshold, y0, y1)
                 be.bloom_h(self.threshold, self.bloom1, r, y0, y1)
+        self._mark("edge_bands_shade_bloomh")
         pending = self.start_halo_exchange()
         if b > a:
             be.shade(frame, self.color, self.threshold, a, b)
             be.bloom_h(self.threshold, self.bloom1, r, a, b)
+        self._mark("interior_shade_bloomh")
         if bottom > top:
             be.bloomv_post(self.bloom1, self.color[top:bottom], self.ldr[top:bottom], lo, hi, row0=top)
+        self._mark("interior_bloomv_post")
         for req in pending:
             req.wait()
+        self._mark("halo_wait")  # what of the exchange the interior work did not hide
         if top > 0:
             be.bloomv_post(self.bloom1, self.color[:top], self.ldr[:top], lo, hi, row0=0)
         if bottom < r:
             be.bloomv_post(self.bloom1, self.color[max(bottom, top):], self.ldr[max(bottom, top):], lo, hi, row0=max(bottom, top))
+        self._mark("edge_bloomv_post")
         return self.ldr
 
     def gather(self, dst: int = 0):
         """Collects the RGBA8 strips of the frame just rendered on rank `dst` (list of tensors there, None
         elsewhere).  With several frames in flight on a GPU the transfer runs on a side stream and the
         next render() goes on at once; the returned tensors are complete once that stream (or the
-        device) is synchronised."""
+        device) is synchronised, and stay untouched until as many further frames as there are frames in
+        flight have been gathered (every output strip of the ring has receive buffers of its own)."""
         ldr = self.ldr
         slot, self._slot = self._slot, (self._slot + 1) % len(self._ring)
         if self.plan.world == 1:
             return [ldr]
         if self._side is None:
-            return self._gather_now(ldr, dst)
+            self._mark("gather_start")
+            parts = self._gather_now(ldr, dst, slot)
+            self._mark("gather")
+            return parts
         rendered = torch.cuda.Event()
         rendered.record()
         with torch.cuda.stream(self._side):
             self._side.wait_event(rendered)
-            parts = self._gather_now(ldr, dst)
+            self._mark("gather_start", self._side)
+            parts = self._gather_now(ldr, dst, slot)
+            self._mark("gather", self._side)
             done = torch.cuda.Event()
             done.record(self._side)
         self._slot_free[slot] = done
         return parts
 
-    def _gather_now(self, ldr, dst: int):
+    def _gather_now(self, ldr, dst: int, slot: int = 0):
         p = self.plan
         if p.rank == dst:
-            if self._gathered is None:
-                self._gathered = [self.backend.empty((StripPlan.make(k, p.world, p.total_rows).rows, self.width, 4), torch.uint8)
-                                  for k in range(p.world)]
-            parts = list(self._gathered)
+            if self._gathered[slot] is None:
+                self._gathered[slot] = [self.backend.empty((StripPlan.make(k, p.world, p.total_rows).rows, self.width, 4), torch.uint8)
+                                        for k in range(p.world)]
+            parts = list(self._gathered[slot])
             ops = [dist.P2POp(dist.irecv, parts[k], k, self.group) for k in range(p.world) if k != dst]
             parts[dst] = ldr
             for req in dist.batch_isend_irecv(ops):
