@@ -65,8 +65,7 @@ typedef struct VkrLightInfo {
 } VkrLightInfo;
 
 /* Which pixels a point light's draw touches (the reference rasterises a sphere mesh per light,
- * GraphicsPipeline.cs:100-117).  Only FULLSCREEN is implemented: it equals the reference
- * whenever the camera is inside every light volume. */
+ * GraphicsPipeline.cs:100-117). */
 #define VKR_COVERAGE_FULLSCREEN 0 /* every light volume covers every pixel (exact while the camera is inside every volume) */
 #define VKR_COVERAGE_MESH 1       /* per-pixel coverage of the light-volume mesh, from vkr_light_coverage() */
 
@@ -339,8 +338,8 @@ VKR_EXPORT int32_t vkr_current_frame(vkr_ctx *ctx);
  * (VulkanRenderer.cs:630-633): it queues a mesh with a material and a model matrix between BeginFrame and
  * EndFrame.  With draw calls in a frame, EndFrame renders the point-light depth cubes and the directional depth
  * map from them (VulkanRenderer.cs:325-376, 406-428); if every draw has a material (material >= 0) and its mesh
- * has attributes, it also renders the G-buffer (VulkanRenderer.cs:378-404).  What is not rendered is taken from
- * the vkr_upload_* calls. */
+ * has attributes, it also renders the G-buffer (VulkanRenderer.cs:378-404); if only some have, EndFrame fails with
+ * VKR_ERR_INVALID.  What is not rendered is taken from the vkr_upload_* calls. */
 VKR_EXPORT int32_t vkr_create_mesh(vkr_ctx *ctx, const float *positions, int32_t n_verts, const uint32_t *indices, int32_t n_tris, int32_t *mesh_out);
 VKR_EXPORT int32_t vkr_set_mesh_attributes(vkr_ctx *ctx, int32_t mesh, const float *texcoords, const float *normals, const float *tangents);
 /* Three single-level RGBA8 images: albedo (_SRGB), normal map (_UNORM), ao/roughness/metalness (_SRGB). */
@@ -349,7 +348,11 @@ VKR_EXPORT int32_t vkr_create_material(vkr_ctx *ctx, const void *albedo, int32_t
                                        const void *arm, int32_t arm_w, int32_t arm_h, int32_t *material_out);
 VKR_EXPORT int32_t vkr_draw_model(vkr_ctx *ctx, int32_t mesh, int32_t material, const float *model16);
 
-/* Images of passes the frame does not render itself (see vkr_draw_model), for the current frame. */
+/* Images of passes the frame does not render itself (see vkr_draw_model), for the current frame slot (there are
+ * frames_in_flight slots; vkr_current_frame() names the one the next EndFrame renders).  An upload stays in its slot
+ * until it is overwritten.  vkr_create and vkr_resize set every slot to the reference's clear values (albedo
+ * (0,0,0,0), normal / arm / position (0,0,0,1), depth 1.0: VulkanRenderer.cs:1155-1161), so a slot nothing was
+ * uploaded to or rendered into shades as an empty scene. */
 VKR_EXPORT int32_t vkr_upload_gbuffer(vkr_ctx *ctx, const void *albedo, const void *normal, const void *arm, const void *position);
 /* An image in place of the skybox draw (VulkanRenderer.cs:436-443) for the current frame.  Without one, EndFrame
  * draws the skybox from the environment cube when there is one (vkr_create_skybox_cubemap / vkr_upload_env_cube)

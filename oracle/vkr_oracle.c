@@ -1420,6 +1420,7 @@ ORC_API void orc_gbuffer(const orc_gpass_args *a)
                     const double zs = fma(e2, tr.z[2], fma(e1, tr.z[1], e0 * tr.z[0]));
                     if (!(zs >= 0.0 && zs <= tr.D)) continue;
                     const float depth = (float)(zs * inv_D) + 0.0f;
+                    if (!(depth < 1.0f)) continue;   /* CompareOp.Less against the cleared depth 1.0 (GraphicsPipeline.cs:71-73) */
                     uint32_t bits; memcpy(&bits, &depth, 4);
                     const uint64_t key = ((uint64_t)bits << 32) | (uint64_t)(base + (uint32_t)t);
                     uint64_t *o = vis + (size_t)y * a->width + x;

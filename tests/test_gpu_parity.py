@@ -991,3 +991,122 @@ def test_renderer_without_a_projection_draws_no_skybox(gpu, oracle):
         r._call(r._lib.vkr_end_frame)
         want_c, _ = oracle.shade(f)
         assert_bits_equal(r.Read(_lib.TARGET_COLOR, 0), want_c, "colour")
+
+
+def test_gbuffer_rejects_fragments_on_the_far_plane(gpu, oracle):
+    """CompareOp.Less against the depth buffer's clear value: a triangle at depth exactly 1.0 leaves the clear values,
+    one a binary32 step nearer is drawn -- kernel and oracle alike."""
+    from tests.test_oracle_kat import _flat_triangle_draw, _identity_scene
+    P = _passes()
+    scene = _identity_scene()
+    flip = bool((oracle.gbuffer([_flat_triangle_draw(0.5, True)], scene, 32, 32)[0][..., 3] != 0).any())
+    for z in (1.0, np.float32(1.0) - np.float32(2.0 ** -24), 0.25):
+        draws = [_flat_triangle_draw(z, flip)]
+        want = oracle.gbuffer(draws, scene, 32, 32)
+        got = P.gbuffer(_gpass_device_draws(draws, gpu), scene, 32, 32, gpu)
+        for name, g, wv in zip(("albedo", "normal", "arm", "position"), got, want):
+            assert_bits_equal(P.f16_bits(g), wv, f"z = {z}: G-buffer {name}")
+        assert bool((want[0][..., 3] != 0).any()) == (z < 1.0)
+
+
+def _small_renderer(w, h, **kw):
+    from vulkanrenderer_amd.renderer import HipRenderer
+    args = dict(max_lights=8, dir_shadow_res=64, point_shadow_res=16, env_res=16, irradiance_res=8, prefilter_res=16, prefilter_mips=1, brdf_lut_res=32)
+    args.update(kw)
+    return HipRenderer(w, h, **args)
+
+
+def test_renderer_end_frame_takes_the_lights_list_and_the_volume_mesh(gpu, oracle):
+    """The public EndFrame(): the `Lights` list is what is drawn, with per-light volume coverage once a volume mesh is
+    set; light records given with SetLightInfos for a frame are not overwritten by the list."""
+    import dataclasses
+    from vulkanrenderer_amd.renderer import Light
+    w, h, nl = 136, 88, 5
+    verts, tris = synth.make_sphere_mesh()
+    f = synth.make_frame(72, w, h, nl, 16, 64, irr_res=8, pref_res=16, lut_res=32)
+    f.scene = _camera_scene((2.0, 1.0, -4.0), aspect=w / h)
+    f.lights = _small_lights(np.random.default_rng(3), nl, 0.03)
+    masks = oracle.light_coverage(f.scene, f.lights, verts, tris, w, h)
+    with _small_renderer(w, h) as r:
+        env = synth.make_env_cube(np.random.default_rng(2), 16)
+        r.UploadEnvironmentCubemap(env)
+        r.CreateIrradianceCubemap(); r.CreatePrefilteredCubemap(); r.CreateBRDFLUTTexture()
+        f.irradiance, f.prefilter, f.brdf_lut = r.Read(_lib.TARGET_IRRADIANCE), r.Read(_lib.TARGET_PREFILTER, mip=0), r.Read(_lib.TARGET_BRDF_LUT)
+        sky = oracle.skybox(env, f.scene, w, h)
+        r.Lights = [Light(tuple(float(v) for v in l["position"]), tuple(float(v) for v in l["color"])) for l in f.lights]
+        for i, l in enumerate(r.Lights):
+            assert l.ToInfo().tobytes() == f.lights[i].tobytes()
+
+        def frame_inputs():
+            r.UpdateSceneInfo(f.scene)
+            r.UploadGBuffer(f.albedo, f.normal, f.arm, f.position)
+            r.UploadDirectionalShadowMap(f.dir_shadow)
+            for i in range(nl):
+                r.UploadPointShadowMap(i, f.cube_shadow[i])
+
+        # slot 0, no volume mesh: every light covers every pixel
+        frame_inputs(); r.BeginFrame(); r.EndFrame()
+        want_c, want_t = oracle.shade(f, sky)
+        assert_bits_equal(r.Read(_lib.TARGET_COLOR, 0), want_c, "Lights list, full coverage: colour")
+        assert_bits_equal(r.Read(_lib.TARGET_THRESHOLD, 0), want_t, "Lights list, full coverage: threshold")
+        # slot 1, volume mesh set: each light's draw covers its volume
+        r.SetLightVolumeMesh(verts, tris)
+        frame_inputs(); r.BeginFrame(); r.EndFrame()
+        mask_c, mask_t = oracle.shade(f, sky, coverage=masks)
+        assert not np.array_equal(mask_c, want_c)
+        assert_bits_equal(r.Read(_lib.TARGET_COLOR, 1), mask_c, "Lights list + volume mesh: colour")
+        assert_bits_equal(r.Read(_lib.TARGET_THRESHOLD, 1), mask_t, "Lights list + volume mesh: threshold")
+        # slot 0 again (its uploads are still there): two explicit records with full coverage survive EndFrame
+        r.UpdateSceneInfo(f.scene)
+        r.SetLightInfos(f.lights[:2], _lib.COVERAGE_FULLSCREEN)
+        r.BeginFrame(); r.EndFrame()
+        two = dataclasses.replace(f, lights=f.lights[:2], cube_shadow=np.ascontiguousarray(f.cube_shadow[:2]))
+        two_c, _ = oracle.shade(two, sky)
+        assert_bits_equal(r.Read(_lib.TARGET_COLOR, 0), two_c, "explicit light records: colour")
+        # and the next frame falls back to the list
+        frame_inputs(); r.BeginFrame(); r.CompositionPass()
+        r.WaitIdle()
+        assert_bits_equal(r.Read(_lib.TARGET_COLOR, 1), mask_c, "CompositionPass with the Lights list: colour")
+
+
+def test_renderer_without_uploads_shades_an_empty_scene(gpu, oracle):
+    """Nothing uploaded, nothing drawn: every frame slot holds the reference's clear values (G-buffer alpha 0, depth
+    1.0), so both slots give the cleared composition image, not whatever the allocations held."""
+    from vulkanrenderer_amd.renderer import Light
+    w, h = 72, 40
+    with _small_renderer(w, h) as r:
+        r.UploadEnvironmentCubemap(synth.make_env_cube(np.random.default_rng(2), 16))
+        r.CreateIrradianceCubemap(); r.CreatePrefilteredCubemap(); r.CreateBRDFLUTTexture()
+        r.Lights = [Light((0.0, 1.0, 0.0), (5.0, 5.0, 5.0))]
+        for slot in (0, 1, 0):
+            assert r.CurrentFrame == slot
+            r.BeginFrame(); r.EndFrame()   # the zeroed SceneInfo has no projection: no skybox either
+            color = r.Read(_lib.TARGET_COLOR, slot)
+            assert (color[..., :3] == 0).all() and (color[..., 3] == 0x3C00).all()
+            assert (r.Read(_lib.TARGET_THRESHOLD, slot)[..., :3] == 0).all()
+            ldr = r.Read(_lib.TARGET_LDR, slot)
+            assert (ldr[..., :3] == 0).all() and (ldr[..., 3] == 255).all()
+        r.Resize(40, 24)
+        r.BeginFrame(); r.EndFrame()
+        color = r.Read(_lib.TARGET_COLOR, 1)
+        assert color.shape == (24, 40, 4) and (color[..., :3] == 0).all() and (color[..., 3] == 0x3C00).all()
+
+
+def test_renderer_refuses_a_frame_whose_draws_are_only_partly_shadeable(gpu):
+    w, h = 64, 40
+    slab = synth.make_scene_mesh(8)
+    uv, nrm, tan = synth.mesh_attributes(*slab, uv_scale=0.25)
+    alb, nmap, arm = synth.make_material(np.random.default_rng(4), 16)
+    with _small_renderer(w, h) as r:
+        r.UploadEnvironmentCubemap(synth.make_env_cube(np.random.default_rng(2), 16))
+        r.CreateIrradianceCubemap(); r.CreatePrefilteredCubemap(); r.CreateBRDFLUTTexture()
+        full = r.CreateMesh(slab[0], slab[1], uv, nrm, tan)
+        bare = r.CreateMesh(slab[0], slab[1])
+        mat = r.CreateMaterial(alb, nmap, arm)
+        r.UpdateSceneInfo(_camera_scene((2.0, 1.6, -4.0), aspect=w / h))
+        r.BeginFrame()
+        r.DrawModel(full, np.eye(4), mat)
+        r.DrawModel(bare, np.eye(4))
+        with pytest.raises(_lib.VkrError) as e:
+            r.EndFrame()
+        assert e.value.code == _lib.VKR_ERR_INVALID and "draw calls have a material" in str(e.value)

@@ -566,3 +566,34 @@ def test_skybox_known_answers(oracle):
     assert (sky_x[2:-2, 2:-2, 0] == 1.0).all() and (sky_x[0, :, 0] != 1.0).all()
     whole = oracle.skybox(env, s, 16, 16)
     assert np.array_equal(oracle.skybox(env, s, 16, 5, frame_rows=16, row0=7), whole[7:12])
+
+
+def _flat_triangle_draw(z, flip=False):
+    """One triangle at clip depth z (identity view and projection: clip = position), with flat attributes and 1x1 textures."""
+    pos = np.array([(-0.6, -0.6, z), (0.6, -0.6, z), (0.0, 0.7, z)], dtype=np.float32)
+    tri = np.array([(0, 2, 1) if flip else (0, 1, 2)], dtype=np.uint32)
+    one = lambda r, g, b: np.array([[[r, g, b, 255]]], dtype=np.uint8)
+    return dict(positions=pos, texcoords=np.zeros((3, 2), np.float32), normals=np.tile(np.float32([0, 0, 1]), (3, 1)),
+                tangents=np.tile(np.float32([1, 0, 0]), (3, 1)), triangles=tri, model=np.eye(4),
+                albedo=one(200, 100, 50), normal=one(128, 128, 255), arm=one(255, 128, 0))
+
+
+def _identity_scene():
+    s = synth.default_scene_info().copy()
+    s["camera_view"] = np.eye(4, dtype=np.float32).ravel()
+    s["camera_projection"] = np.eye(4, dtype=np.float32).ravel()
+    return s
+
+
+def test_gbuffer_depth_test_is_less_against_a_buffer_cleared_to_one(oracle):
+    """GraphicsPipeline.cs:71-73 + the depth attachment's clear value 1.0 (VulkanRenderer.cs:1155-1161): a fragment
+    exactly on the far plane (depth 1.0) fails CompareOp.Less and leaves the clear values; just inside it is drawn."""
+    scene = _identity_scene()
+    drawn = [oracle.gbuffer([_flat_triangle_draw(0.5, flip)], scene, 32, 32)[0][..., 3] != 0 for flip in (False, True)]
+    assert drawn[0].any() != drawn[1].any(), "exactly one winding faces the camera"
+    flip = bool(drawn[1].any())
+    near = oracle.gbuffer([_flat_triangle_draw(np.float32(1.0) - np.float32(2.0 ** -24), flip)], scene, 32, 32)
+    assert np.array_equal(near[0][..., 3] != 0, drawn[int(flip)])
+    far = oracle.gbuffer([_flat_triangle_draw(1.0, flip)], scene, 32, 32)
+    assert not (far[0] != 0).any(), "a fragment at depth 1.0 must not pass LESS against the cleared depth"
+    assert (far[1][..., 3] == 0x3C00).all() and not (far[1][..., :3] != 0).any()

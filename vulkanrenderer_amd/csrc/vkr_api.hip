@@ -98,6 +98,45 @@ static int32_t alloc_frame_sized(vkr_ctx *c)
     return VKR_OK;
 }
 
+// What the reference's render passes clear their attachments to (VulkanRenderer.cs:1155-1161: albedo (0,0,0,0),
+// normal / arm / position (0,0,0,1); depth 1.0), so that a frame slot nothing was uploaded to or rendered into
+// shades as an empty scene instead of whatever the allocation held.
+static constexpr unsigned long long RGBA16F_0001 = 0x3C00000000000000ull;  // binary16 (0, 0, 0, 1)
+static constexpr unsigned long long D32F_ONE_PAIR = 0x3F8000003F800000ull;  // two texels of depth 1.0
+static constexpr unsigned long long D32F_25_PAIR = 0x41C8000041C80000ull;   // two texels of 25 x 1.0 (the _X25 layout)
+
+static int32_t clear_frame_sized(vkr_ctx *c)
+{
+    const size_t px = (size_t)c->cfg.width * c->cfg.height;
+    for (Frame &f : c->frames) {
+        int32_t rc = fill_u64(f.gbuf[0], px, 0ull, c->stream);
+        for (int k = 1; k < 4 && rc == VKR_OK; k++) rc = fill_u64(f.gbuf[k], px, RGBA16F_0001, c->stream);
+        void *imgs[] = {f.background, f.color, f.threshold, f.bloom1, f.bloom2};
+        for (void *img : imgs) if (rc == VKR_OK) rc = fill_u64(img, px, RGBA16F_0001, c->stream);
+        if (rc == VKR_OK) rc = fill_u64(f.ldr, px / 2, 0xFF000000FF000000ull, c->stream);
+        if (rc != VKR_OK) return rc;
+        if (px & 1) VKR_HIP_CHECK(hipMemsetAsync((char *)f.ldr + (px - 1) * 4, 0, 4, c->stream));
+    }
+    VKR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return VKR_OK;
+}
+
+static int32_t clear_shadow_maps(vkr_ctx *c)
+{
+    const size_t dir = (size_t)c->cfg.dir_shadow_res * c->cfg.dir_shadow_res;
+    const size_t cube = (size_t)c->cfg.max_lights * 6 * c->cfg.point_shadow_res * c->cfg.point_shadow_res;
+    for (Frame &f : c->frames) {
+        int32_t rc = fill_u64(f.dir_shadow, dir / 2, D32F_ONE_PAIR, c->stream);
+        if (rc == VKR_OK) rc = fill_u64(f.cube_shadow, cube / 2, c->cubes_tiled ? D32F_25_PAIR : D32F_ONE_PAIR, c->stream);
+        if (rc != VKR_OK) return rc;
+        const float one = 1.0f;  // a map with an odd number of texels: the last one
+        if (dir & 1) VKR_HIP_CHECK(hipMemcpyAsync(f.dir_shadow + dir - 1, &one, 4, hipMemcpyHostToDevice, c->stream));
+        if (cube & 1) VKR_HIP_CHECK(hipMemcpyAsync(f.cube_shadow + cube - 1, &one, 4, hipMemcpyHostToDevice, c->stream));
+        VKR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    return VKR_OK;
+}
+
 static void destroy(vkr_ctx *c)
 {
     if (!c) return;
@@ -169,10 +208,18 @@ static constexpr int GP_MAX_DRAWS = 1024;  // draw records the geometry-pass wor
 static int32_t run_geometry_pass(vkr_ctx *c, Frame &f)
 {
     if (c->draw_calls.empty()) return VKR_OK;
+    // Either every draw of the frame can be shaded (material and vertex attributes) and the pass runs, or none can
+    // and the draws only cast shadows over an uploaded G-buffer.  A mixture would silently drop geometry.
+    size_t shadeable = 0;
+    for (size_t k = 0; k < c->draw_calls.size(); k++)
+        if (c->draw_material[k] >= 0 && c->meshes[c->draw_mesh[k]].texcoords) shadeable++;
+    if (shadeable == 0) return VKR_OK;
+    if (shadeable != c->draw_calls.size())
+        return fail(VKR_ERR_INVALID, "%zu of the frame's %zu draw calls have a material and vertex attributes and the rest do not: "
+                    "the geometry pass needs them for every draw (or for none, with the G-buffer uploaded)", shadeable, c->draw_calls.size());
     std::vector<VkrGpassDraw> draws(c->draw_calls.size());
     for (size_t k = 0; k < draws.size(); k++) {
         const vkr_ctx::Mesh &m = c->meshes[c->draw_mesh[k]];
-        if (c->draw_material[k] < 0 || !m.texcoords) return VKR_OK;
         const vkr_ctx::Material &mat = c->materials[c->draw_material[k]];
         VkrGpassDraw &d = draws[k];
         d.positions = m.positions; d.texcoords = m.texcoords; d.normals = m.normals; d.tangents = m.tangents;
@@ -324,6 +371,8 @@ extern "C" int32_t vkr_create(const VkrConfig *config, vkr_ctx **out)
         }
         c->cubes_tiled = cfg.point_shadow_res % 8 == 0;
         if (c->cubes_tiled) VKR_HIP_CHECK(hipMalloc((void **)&c->cube_staging, (size_t)6 * cfg.point_shadow_res * cfg.point_shadow_res * 4));
+        if ((r = clear_frame_sized(c)) != VKR_OK) return r;
+        if ((r = clear_shadow_maps(c)) != VKR_OK) return r;
         VKR_HIP_CHECK(hipMalloc(&c->env, cube_bytes(cfg.env_res)));
         if (cfg.env_res % 4 == 0) VKR_HIP_CHECK(hipMalloc(&c->env_tiled, cube_bytes(cfg.env_res)));
         VKR_HIP_CHECK(hipMalloc(&c->irradiance, cube_bytes(cfg.irradiance_res)));
@@ -353,7 +402,8 @@ extern "C" int32_t vkr_resize(vkr_ctx *c, int32_t width, int32_t height)
     c->cfg.width = width; c->cfg.height = height;
     c->timing_valid = false;
     if (c->gp_workspace) { (void)hipFree(c->gp_workspace); c->gp_workspace = nullptr; }
-    return alloc_frame_sized(c);
+    int32_t rc = alloc_frame_sized(c);
+    return rc == VKR_OK ? clear_frame_sized(c) : rc;
 }
 
 extern "C" int32_t vkr_update_scene_info(vkr_ctx *c, const VkrSceneInfo *info)

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void gpass_visibility_kernel(const GpassParams
         const double zs = __builtin_fma(e2, tr.z[2], __builtin_fma(e1, tr.z[1], e0 * tr.z[0]));
         if (!(zs >= 0.0 && zs <= tr.D)) return;
         const float depth = (float)(zs * tr.inv_D) + 0.0f;
+        if (!(depth < 1.0f)) return;  // CompareOp.Less against the depth buffer's clear value 1.0
         const unsigned long long key = ((unsigned long long)__builtin_bit_cast(unsigned int, depth) << 32) | (unsigned long long)id;
         atomicMin(p.vis + (size_t)y * p.width + x, key);
     });
@@ -218,10 +219,17 @@ __global__ __launch_bounds__(256) void skybox_kernel(const SkyboxParams p)
     p.out[(size_t)y * p.width + x] = pack4(c.x, c.y, c.z, 1.0f);
 }
 
-__global__ __launch_bounds__(256) void fill_u64_kernel(unsigned long long *out, size_t n)
+__global__ __launch_bounds__(256) void fill_u64_kernel(unsigned long long *out, size_t n, unsigned long long value)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = ~0ull;
+    if (i < n) out[i] = value;
+}
+
+int32_t fill_u64(void *dst, size_t n, unsigned long long value, void *stream)
+{
+    if (n == 0) return VKR_OK;
+    hipLaunchKernelGGL(fill_u64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), (unsigned long long *)dst, n, value);
+    return launch_status("fill");
 }
 
 }  // namespace vkr
@@ -272,7 +280,7 @@ static int32_t launch_gbuffer(const char *who, const VkrGpassArgs *a, unsigned l
     p.width = a->width; p.rows = a->rows; p.frame_rows = a->frame_rows; p.row0 = a->row0;
     p.albedo = (uint2 *)a->albedo; p.normal = (uint2 *)a->normal; p.arm = (uint2 *)a->arm; p.position = (uint2 *)a->position;
     p.draw = 0; p.tri_base = 0;
-    hipLaunchKernelGGL(fill_u64_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, as_stream(stream), p.vis, npx);
+    hipLaunchKernelGGL(fill_u64_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, as_stream(stream), p.vis, npx, ~0ull);
     unsigned base = 0;
     for (int d = 0; d < a->n_draws; d++) {
         if (a->draws[d].n_tris > 0) {

@@ -24,6 +24,9 @@ int32_t fail(int32_t code, const char *fmt, ...) __attribute__((format(printf, 2
         if (!(cond)) return vkr::fail(VKR_ERR_INVALID, __VA_ARGS__); \
     } while (0)
 
+// Stores `value` into n consecutive 64-bit words of device memory (one RGBA16F texel or two D32F texels each).
+int32_t fill_u64(void *dst, size_t n, unsigned long long value, void *stream);
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Checks the status of the launch that was just issued.

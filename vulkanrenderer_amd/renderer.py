@@ -78,6 +78,8 @@ class HipRenderer:
         self.prefilter_mips = prefilter_mips or 5
         self.brdf_lut_res = brdf_lut_res or 512
         self.Lights: list[Light] = []
+        self._explicit_lights = False   # SetLightInfos was called for the frame being built: EndFrame keeps those records
+        self._has_volume_mesh = False
 
     # ---- lifetime (IDisposable in the reference) ----------------------------------------------
     def Dispose(self) -> None:
@@ -114,20 +116,31 @@ class HipRenderer:
 
     def EndFrame(self) -> None:
         """Uploads the light list (draw order = list order), then runs composition, bloom 1, bloom 2 and
-        post-process for the current frame and advances the frame index."""
+        post-process for the current frame and advances the frame index.  Light records given with
+        SetLightInfos since the last EndFrame take the place of the `Lights` list for this frame."""
         self._set_lights()
         self._call(self._lib.vkr_end_frame)
+        self._explicit_lights = False
 
     def _set_lights(self) -> None:
+        """`Lights` -> LightInfo records; once a light-volume mesh is set, each light's draw covers the pixels
+        of its volume (what rasterising sphereMesh per light does in the reference), before that every pixel."""
+        if self._explicit_lights:
+            return
         infos = np.zeros(len(self.Lights), dtype=LIGHT_DTYPE)
         for i, light in enumerate(self.Lights):
             infos[i] = light.ToInfo()
-        self.SetLightInfos(infos)
+        self._push_lights(infos, _lib.COVERAGE_MESH if self._has_volume_mesh else _lib.COVERAGE_FULLSCREEN)
 
-    def SetLightInfos(self, infos: np.ndarray, coverage: int = _lib.COVERAGE_FULLSCREEN) -> None:
-        assert infos.dtype == LIGHT_DTYPE
+    def _push_lights(self, infos: np.ndarray, coverage: int) -> None:
         infos = np.ascontiguousarray(infos)
         self._call(self._lib.vkr_set_lights, _host_ptr(infos) if len(infos) else C.c_void_p(0), len(infos), coverage)
+
+    def SetLightInfos(self, infos: np.ndarray, coverage: int = _lib.COVERAGE_FULLSCREEN) -> None:
+        """Raw LightInfo records and a coverage mode for the frame being built, instead of the `Lights` list."""
+        assert infos.dtype == LIGHT_DTYPE
+        self._push_lights(infos, coverage)
+        self._explicit_lights = True
 
     def CreateMesh(self, verts: np.ndarray, triangles: np.ndarray, texcoords=None, normals=None, tangents=None) -> int:
         """Keeps a mesh on the device (Mesh.cs); returns its handle for DrawModel.  With texture coordinates,
@@ -166,6 +179,7 @@ class HipRenderer:
         verts = np.ascontiguousarray(verts, dtype=np.float32)
         triangles = np.ascontiguousarray(triangles, dtype=np.uint32)
         self._call(self._lib.vkr_set_light_volume_mesh, _host_ptr(verts), len(verts), _host_ptr(triangles), len(triangles))
+        self._has_volume_mesh = True
 
     def WaitIdle(self) -> None:
         self._call(self._lib.vkr_sync)
