@@ -292,39 +292,54 @@ __global__ __launch_bounds__(256) void prefilter_texel_kernel(const void *env, i
 }
 
 // brdf.frag:81-119, one lane per texel; a workgroup works on one row (one roughness).
+// The half vector of sample s depends on the sample and on the roughness only, not on N.V: with N = (0,0,1)
+// the shader's tangent frame is (0,-1,0), (1,0,-0) (brdf.frag:52-56), so its sampleVec is (hy, -hx, hz).  The
+// workgroup normalises the row's 1024 half vectors once into LDS; the sample loop then reads one broadcast
+// 16-byte entry per sample and does only the work that depends on the lane's N.V.
+#ifndef VKR_LUT_UNROLL
+#define VKR_LUT_UNROLL 4
+#endif
 __global__ __launch_bounds__(256) void brdf_lut_kernel(uint32_t *out, int n, int row_begin, int row_end)
 {
-    __shared__ float2 theta_cs[SAMPLE_COUNT];
+    __shared__ float4 half_vec[SAMPLE_COUNT];  // normalised H and N.H = max(H.z, 0)
     int row = row_begin + blockIdx.y;
     float rn = rcp_rn((float)n);
     float rough = ((float)row + 0.5f) * rn;
-    for (int s = threadIdx.x; s < SAMPLE_COUNT; s += 256) theta_cs[s] = ggx_theta(s, rough);
+    for (int s = threadIdx.x; s < SAMPLE_COUNT; s += 256) {
+        float2 pcs = g_hammersley_cs[s];
+        float2 tcs = ggx_theta(s, rough);
+        float hx = pcs.x * tcs.y, hy = pcs.y * tcs.y, hz = tcs.x;
+        f3 H = normalize3_fast(mk3(hy, -hx, hz));
+        half_vec[s] = make_float4(H.x, H.y, H.z, max0(H.z));
+    }
     __syncthreads();
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n || row >= row_end) return;
     float NdotV = ((float)i + 0.5f) * rn;
-    float Vx = sqrt_rn(fma_(-NdotV, NdotV, 1.0f)), Vz = NdotV;
+    float Vx = sqrt_rn(fma_(-NdotV, NdotV, 1.0f)), Vz = NdotV;  // V.y = 0 drops out of dot(V,H) and of L.y
     float k = (rough * rough) * 0.5f;
-    float gV = max0(Vz) * rcp_rn(fma_(max0(Vz), 1.0f - k, k));  // GeometrySchlickGGX(NdotV), brdf.frag:60-69
+    float one_minus_k = 1.0f - k;
+    float gV = max0(Vz) * rcp_rn(fma_(max0(Vz), one_minus_k, k));  // GeometrySchlickGGX(NdotV), brdf.frag:60-69
     float A = 0.0f, B = 0.0f;
+#pragma unroll VKR_LUT_UNROLL
     for (int s = 0; s < SAMPLE_COUNT; s++) {
-        float2 pcs = g_hammersley_cs[s];
-        float2 tcs = theta_cs[s];
-        float hx = pcs.x * tcs.y, hy = pcs.y * tcs.y, hz = tcs.x;
-        // with N = (0,0,1): tangent = (0,-1,0), bitangent = (1,0,-0) (brdf.frag:52-56), so
-        // sampleVec = (hy, -hx, hz); V.y = 0 drops out of dot(V,H) and of L.y
-        f3 H = normalize3_fast(mk3(hy, -hx, hz));
+        const float4 H = half_vec[s];
         float vh = fma_(Vz, H.z, Vx * H.x);
         float vh2 = 2.0f * vh;
-        f3 L = normalize3_fast(mk3(fma_(vh2, H.x, -Vx), vh2 * H.y, fma_(vh2, H.z, -Vz)));
-        float NdotL = max0(L.z), NdotH = max0(H.z), VdotH = max0(vh);
-        if (NdotL > 0.0f) {
-            float G = (NdotL * rcp_rn_checked(fma_(NdotL, 1.0f - k, k))) * gV;
-            float G_vis = (G * VdotH) * rcp_rn_checked(NdotH * NdotV);
-            float Fc = pow5(1.0f - VdotH);
-            A = fma_(1.0f - Fc, G_vis, A);
-            B = fma_(Fc, G_vis, B);
-        }
+        // L = normalize(2 (V.H) H - V): V and H are unit vectors up to rounding, so |L|^2 is within a few ulps of 1
+        // and the short square-root / reciprocal sequences are inside their exact domain (same bits as the IEEE ones)
+        f3 Lr = mk3(fma_(vh2, H.x, -Vx), vh2 * H.y, fma_(vh2, H.z, -Vz));
+        float Lz = Lr.z * fast_rcp_rn(fast_sqrt_rn(dot3(Lr, Lr)));
+        float NdotL = max0(Lz), NdotH = H.w, VdotH = max0(vh);
+        // denominators: N.L (1-k) + k lies in [k, 1] with k >= 1/(8 n^2); N.H >= 1/32 for every sample (xi <= 1023/1024)
+        // and N.V >= 1/(2n): both are normal numbers with normal reciprocals
+        float G = (NdotL * fast_rcp_rn(fma_(NdotL, one_minus_k, k))) * gV;
+        float G_vis = (G * VdotH) * fast_rcp_rn(NdotH * NdotV);
+        float Fc = pow5(1.0f - VdotH);
+        // a sample the shader skips (N.L <= 0) adds x * 0 to sums that are never negative: their bits stay as they are
+        G_vis = NdotL > 0.0f ? G_vis : 0.0f;
+        A = fma_(1.0f - Fc, G_vis, A);
+        B = fma_(Fc, G_vis, B);
     }
     half2_t o; o.x = to_f16(A * (1.0f / 1024.0f)); o.y = to_f16(B * (1.0f / 1024.0f));
     out[(size_t)row * n + i] = __builtin_bit_cast(uint32_t, o);
