@@ -267,6 +267,23 @@ typedef struct VkrBloomPostArgs {
 } VkrBloomPostArgs;
 VKR_EXPORT int32_t vkr_bloomv_postprocess(const VkrBloomPostArgs *args, void *stream);
 
+/* Both bloom_blur.frag draws and the postprocess.frag draw (VulkanRenderer.cs:504-557) in one kernel: same
+ * results as vkr_bloom_blur (horizontal, then vertical) followed by vkr_postprocess, bit for bit, but neither
+ * bloom image is stored (20 bytes per pixel move instead of 36).  `threshold` is the source of bloom pass 1
+ * (the composition pass's second attachment), addressed like VkrBloomArgs.src: output row r is centred on
+ * source row r + src_row_offset, so a strip passes its threshold rows plus four halo rows on each side.
+ * Pass 1 wraps along x by wrap_h (the reference: VKR_WRAP_REPEAT), pass 2 along y by wrap_v over source rows
+ * (the reference: VKR_WRAP_CLAMP with the valid row range of `threshold`). */
+typedef struct VkrBloomChainArgs {
+    const void *threshold; const void *hdr; void *out_rgba8;
+    int32_t width, rows;
+    int32_t src_rows, src_row_offset;
+    int32_t wrap_h, clamp_lo_h, clamp_hi_h;
+    int32_t wrap_v, clamp_lo_v, clamp_hi_v;
+    int32_t flags;                              /* VKR_POST_* */
+} VkrBloomChainArgs;
+VKR_EXPORT int32_t vkr_bloom_postprocess(const VkrBloomChainArgs *args, void *stream);
+
 /* IBL precompute.  Cube images are addressed by "face rows": row r of a 6*n-row image is row
  * r % n of face r / n; [row_begin, row_end) selects the part this call computes, so the faces
  * can be split over GPUs. */
@@ -330,7 +347,8 @@ VKR_EXPORT int32_t vkr_set_lights(vkr_ctx *ctx, const VkrLightInfo *lights, int3
  * sphere of 559 vertices / 960 triangles, VulkanRenderer.cs:78,269); needed for VKR_COVERAGE_MESH. */
 VKR_EXPORT int32_t vkr_set_light_volume_mesh(vkr_ctx *ctx, const float *verts, int32_t n_verts, const uint32_t *indices, int32_t n_tris);
 VKR_EXPORT int32_t vkr_begin_frame(vkr_ctx *ctx);                                                /* BeginFrame, :286-318 */
-/* EndFrame, :320-623: composition pass, bloom 1, bloom 2, post-process, then advances the frame index. */
+/* EndFrame, :320-623: composition pass, bloom 1, bloom 2, post-process, then advances the frame index.  The two
+ * bloom images are not stored (VKR_TARGET_BLOOM1 / _BLOOM2 exist only after vkr_pass_bloom). */
 VKR_EXPORT int32_t vkr_end_frame(vkr_ctx *ctx);
 VKR_EXPORT int32_t vkr_current_frame(vkr_ctx *ctx);
 
@@ -377,7 +395,8 @@ VKR_EXPORT int32_t vkr_pass_postprocess(vkr_ctx *ctx);
 VKR_EXPORT int32_t vkr_read(vkr_ctx *ctx, int32_t frame, int32_t target, int32_t mip, void *host, int64_t host_bytes);
 VKR_EXPORT int32_t vkr_sync(vkr_ctx *ctx); /* WaitIdle */
 
-/* Milliseconds the passes of the most recent EndFrame took on the device (HIP events). */
+/* Milliseconds the passes of the most recent EndFrame took on the device (HIP events).  EndFrame runs both bloom
+ * passes and the post-process draw as one kernel: its time is bloom_v_post_ms, and bloom_h_ms is 0. */
 typedef struct VkrTiming {
     float shade_ms, bloom_h_ms, bloom_v_post_ms, frame_ms;
 } VkrTiming;

@@ -55,6 +55,15 @@ __global__ __launch_bounds__(256) void rate_kernel(float *out, float a, float b)
             if (MODE == 29) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(x[k]) : "v"(dd[k]));
             if (MODE == 30) asm volatile("v_readlane_b32 %0, %1, 5" : "=s"(sg[k]) : "v"(x[k]));
             if (MODE == 31) asm volatile("v_cmp_ge_f64 %0, %1, %2" : "=s"(m[k]) : "v"(dd[k]), "v"(da));
+            if (MODE == 32) asm volatile("v_cvt_f16_f32 %0, %0" : "+v"(x[k]));
+            if (MODE == 33) asm volatile("v_cvt_f32_f16 %0, %0" : "+v"(x[k]));
+            if (MODE == 34) asm volatile("v_pack_b32_f16 %0, %0, %1" : "+v"(n[k]) : "v"(a));
+            if (MODE == 35) asm volatile("v_log_f32 %0, %0" : "+v"(x[k]));
+            if (MODE == 36) asm volatile("v_exp_f32 %0, %0" : "+v"(x[k]));
+            if (MODE == 37) asm volatile("v_cvt_u32_f32 %0, %0" : "+v"(x[k]));
+            if (MODE == 38) asm volatile("v_lshl_or_b32 %0, %0, 8, %1" : "+v"(n[k]) : "v"(n[0]));
+            if (MODE == 39) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x[k]) : "v"(n[k]), "s"(a));
+            if (MODE == 40) asm volatile("v_fma_f32 %0, %0, %1, %2 clamp" : "+v"(x[k]) : "v"(a), "v"(b));
             if (MODE == 11) asm volatile("v_cvt_f16_f32 %0, %0\n\tv_cvt_f32_f16 %0, %0" : "+v"(x[k]));
         }
     }
@@ -120,5 +129,14 @@ int main()
     run<29>("v_cvt_f32_f64", out, 1);
     run<30>("v_readlane_b32", out, 1);
     run<31>("v_cmp_ge_f64 -> sgpr", out, 1);
+    run<32>("v_cvt_f16_f32", out, 1);
+    run<33>("v_cvt_f32_f16", out, 1);
+    run<34>("v_pack_b32_f16", out, 1);
+    run<35>("v_log_f32", out, 1);
+    run<36>("v_exp_f32", out, 1);
+    run<37>("v_cvt_u32_f32", out, 1);
+    run<38>("v_lshl_or_b32", out, 1);
+    run<39>("v_fma_mix_f32 f16hi,sgpr,f32", out, 2);
+    run<40>("v_fma_f32 clamp", out, 2);
     return 0;
 }

@@ -136,6 +136,48 @@ def test_fused_bloomv_postprocess_equals_unfused(gpu, w, h):
     assert torch.equal(out_a, out_b)
 
 
+@pytest.mark.parametrize("w,h", [(256, 50), (77, 31), (3, 3), (130, 9), (1, 1), (384, 100), (258, 20)])
+@pytest.mark.parametrize("wrap_h,wrap_v", [(0, 1), (1, 0)])
+def test_one_kernel_bloom_chain_equals_three_passes(gpu, w, h, wrap_h, wrap_v):
+    """vkr_bloom_postprocess against vkr_bloom_blur x2 + vkr_postprocess (themselves held to the oracle above):
+    ragged widths, images smaller than the blur radius, tiles that cross the right edge, both wraps on both axes."""
+    torch, P = _torch(), _passes()
+    thr = P.to_device_f16(_random_hdr(5 + w, h, w), gpu)
+    hdr = P.to_device_f16(_random_hdr(6 + h, h, w, 8.0), gpu)
+    b1, b2 = torch.empty_like(thr), torch.empty_like(thr)
+    out_a = torch.empty((h, w, 4), dtype=torch.uint8, device=gpu)
+    out_b = torch.full_like(out_a, 7)
+    P.bloom_blur(thr, b1, True, wrap_h)
+    P.bloom_blur(b1, b2, False, wrap_v)
+    P.postprocess(hdr, b2, out_a)
+    P.bloom_postprocess(thr, hdr, out_b, wrap_h=wrap_h, wrap_v=wrap_v)
+    assert torch.equal(out_a, out_b)
+
+
+def test_one_kernel_bloom_chain_on_a_strip_with_halo_rows(gpu):
+    """A strip hands the kernel its threshold rows plus four halo rows on each side; rows beyond the frame clamp."""
+    torch, P = _torch(), _passes()
+    w, h = 200, 96
+    thr = P.to_device_f16(_random_hdr(11, h, w), gpu)
+    hdr = P.to_device_f16(_random_hdr(12, h, w, 8.0), gpu)
+    whole = torch.empty((h, w, 4), dtype=torch.uint8, device=gpu)
+    P.bloom_postprocess(thr, hdr, whole)
+    for (a, b) in ((0, 40), (40, 77), (77, 96)):
+        lo, hi = max(a - 4, 0), min(b + 4, h)
+        src = thr[lo:hi].contiguous()
+        out = torch.empty((b - a, w, 4), dtype=torch.uint8, device=gpu)
+        P.bloom_postprocess(src, hdr[a:b].contiguous(), out, src_row_offset=a - lo)
+        assert torch.equal(out, whole[a:b]), f"rows {a}..{b}"
+    # srgb target flag
+    out_a, out_b = torch.empty_like(whole), torch.empty_like(whole)
+    b1, b2 = torch.empty_like(thr), torch.empty_like(thr)
+    P.bloom_blur(thr, b1, True, _lib.WRAP_REPEAT)
+    P.bloom_blur(b1, b2, False, _lib.WRAP_CLAMP)
+    P.postprocess(hdr, b2, out_a, _lib.POST_SRGB_TARGET)
+    P.bloom_postprocess(thr, hdr, out_b, _lib.POST_SRGB_TARGET)
+    assert torch.equal(out_a, out_b)
+
+
 def test_brdf_lut_bit_exact(gpu, oracle):
     torch, P = _torch(), _passes()
     n = 48
@@ -226,7 +268,8 @@ def test_renderer_end_frame_matches_oracle_chain(gpu, oracle):
             r._call(r._lib.vkr_end_frame)
             assert_bits_equal(r.Read(_lib.TARGET_COLOR, frame), want["color"], "colour")
             assert_bits_equal(r.Read(_lib.TARGET_THRESHOLD, frame), want["threshold"], "threshold")
-            assert_bits_equal(r.Read(_lib.TARGET_BLOOM1, frame), want["bloom1"], "bloom 1")
+            with pytest.raises(_lib.VkrError):  # EndFrame stores neither bloom image
+                r.Read(_lib.TARGET_BLOOM1, frame)
             ldr = r.Read(_lib.TARGET_LDR, frame)
             assert np.abs(ldr.astype(np.int32) - want["ldr"].astype(np.int32)).max() <= 1
         # order errors, as the reference throws them (VulkanRenderer.cs:288,322)
@@ -255,9 +298,9 @@ def test_strip_pair_with_local_halo_copy_matches_whole_frame(gpu, oracle):
             p, r = self.plan, self.plan.rows
             if not p.is_top:
                 up = self.peers[p.rank - 1]
-                self.bloom1[0:HALO] = up.bloom1[up.plan.rows:up.plan.rows + HALO]
+                self.threshold_padded[0:HALO] = up.threshold_padded[up.plan.rows:up.plan.rows + HALO]
             if not p.is_bottom:
-                self.bloom1[r + HALO:r + 2 * HALO] = self.peers[p.rank + 1].bloom1[HALO:2 * HALO]
+                self.threshold_padded[r + HALO:r + 2 * HALO] = self.peers[p.rank + 1].threshold_padded[HALO:2 * HALO]
             return []
 
     plans = [StripPlan.make(k, world, h) for k in range(world)]
@@ -265,9 +308,8 @@ def test_strip_pair_with_local_halo_copy_matches_whole_frame(gpu, oracle):
     rs = [Paired(p, w, device=gpu) for p in plans]
     for r in rs:
         r.peers = rs
-    for r, d in zip(rs, frames):  # pass-1 images first: a strip reads its neighbour's boundary rows
+    for r, d in zip(rs, frames):  # thresholded images first: a strip reads its neighbour's boundary rows
         r.backend.shade(d, r.color, r.threshold)
-        r.backend.bloom_h(r.threshold, r.bloom1, r.plan.rows)
     ldr = torch.cat([r.render(d) for r, d in zip(rs, frames)], 0).cpu().numpy()
     color = np.concatenate([P.f16_bits(r.color) for r in rs], 0)
     assert_bits_equal(color, want["color"], "colour of the two strips")

@@ -54,19 +54,15 @@ class OracleBackend:
         frame.coverage_masks = oracle.light_coverage(frame.scene, frame.lights, verts, tris, frame.width, frame.height, frame_rows, row0)
         return frame
 
-    def bloom_h(self, thr, bloom1, rows, y0=0, y1=None):
+    def bloom_post(self, thr, hdr, out, lo, hi, row0=0):
         from tests import oracle
-        y1 = rows if y1 is None else y1
-        self._bits(bloom1)[HALO + y0:HALO + y1] = oracle.bloom_blur(np.ascontiguousarray(self._bits(thr)[y0:y1]), True, oracle.WRAP_REPEAT)
-
-    def bloomv_post(self, bloom1, hdr, out, lo, hi, row0=0):
-        from tests import oracle
-        b = self._bits(bloom1)
+        t = self._bits(thr)
         rows = hdr.shape[0]
-        # vertical blur of output row k centred on source row k + row0 + HALO, taps clamped to [lo, hi]
+        # pass 1 on the rows the vertical taps reach (row k of the output is centred on row k + row0 + HALO of
+        # `thr`, taps clamped to [lo, hi]), then pass 2 over that stack, whose edges are already clamped
         idx = np.clip(np.arange(-4, rows + 4) + HALO + row0, lo, hi)
-        padded = np.ascontiguousarray(b[idx])                       # rows + 8 rows, edges already clamped
-        b2 = oracle.bloom_blur(padded, False, oracle.WRAP_CLAMP)[4:4 + rows]
+        b1 = oracle.bloom_blur(np.ascontiguousarray(t[idx]), True, oracle.WRAP_REPEAT)
+        b2 = oracle.bloom_blur(b1, False, oracle.WRAP_CLAMP)[4:4 + rows]
         out.numpy()[...] = oracle.postprocess(np.ascontiguousarray(self._bits(hdr)), np.ascontiguousarray(b2))
 
 

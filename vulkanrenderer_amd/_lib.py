@@ -116,6 +116,13 @@ class BloomPostArgs(C.Structure):
                 ("wrap", C.c_int32), ("clamp_lo", C.c_int32), ("clamp_hi", C.c_int32), ("flags", C.c_int32)]
 
 
+class BloomChainArgs(C.Structure):
+    _fields_ = [("threshold", C.c_void_p), ("hdr", C.c_void_p), ("out_rgba8", C.c_void_p),
+                ("width", C.c_int32), ("rows", C.c_int32), ("src_rows", C.c_int32), ("src_row_offset", C.c_int32),
+                ("wrap_h", C.c_int32), ("clamp_lo_h", C.c_int32), ("clamp_hi_h", C.c_int32),
+                ("wrap_v", C.c_int32), ("clamp_lo_v", C.c_int32), ("clamp_hi_v", C.c_int32), ("flags", C.c_int32)]
+
+
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "device", "width", "height", "max_lights", "dir_shadow_res", "point_shadow_res", "env_res",
@@ -146,6 +153,7 @@ PROTOTYPES = {
     "vkr_bloom_blur": [C.POINTER(BloomArgs), _vp],
     "vkr_postprocess": [_vp, _vp, _vp, _i32, _i32, _i32, _vp],
     "vkr_bloomv_postprocess": [C.POINTER(BloomPostArgs), _vp],
+    "vkr_bloom_postprocess": [C.POINTER(BloomChainArgs), _vp],
     "vkr_ibl_equirect_to_cube": [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp],
     "vkr_ibl_irradiance": [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp],
     "vkr_ibl_prefilter": [_vp, _i32, _i32, _vp, _i32, _f, _i32, _i32, _vp],

@@ -33,7 +33,7 @@ struct Frame {
     VkrSceneInfo scene;
     void *color = nullptr, *threshold = nullptr, *bloom1 = nullptr, *bloom2 = nullptr, *ldr = nullptr;
     uint64_t *coverage_buf = nullptr;  // light-volume masks, max_lights * tiles
-    bool bloom2_valid = false;
+    bool bloom1_valid = false, bloom2_valid = false;  // stored only by vkr_pass_bloom
 };
 
 }  // namespace vkr
@@ -77,7 +77,7 @@ static void free_frame_sized(vkr_ctx *c)
         void **imgs[] = {&f.background, &f.color, &f.threshold, &f.bloom1, &f.bloom2, &f.ldr, (void **)&f.coverage_buf};
         for (void **p : imgs) { if (*p) (void)hipFree(*p); *p = nullptr; }
         f.has_background = false;
-        f.bloom2_valid = false;
+        f.bloom1_valid = f.bloom2_valid = false;
     }
 }
 
@@ -688,7 +688,7 @@ extern "C" int32_t vkr_pass_bloom(vkr_ctx *c, int32_t horizontal)
     Frame &f = c->frames[c->frame];
     VkrBloomArgs b = bloom_args(c, f, horizontal != 0);
     int32_t rc = vkr_bloom_blur(&b, c->stream);
-    if (rc == VKR_OK && !horizontal) f.bloom2_valid = true;
+    if (rc == VKR_OK) (horizontal ? f.bloom1_valid : f.bloom2_valid) = true;
     return rc;
 }
 
@@ -715,19 +715,18 @@ extern "C" int32_t vkr_end_frame(vkr_ctx *c)
     if ((rc = run_skybox(c, f)) != VKR_OK) return rc;
     if ((rc = vkr_shade(&a, c->stream)) != VKR_OK) return rc;
     VKR_HIP_CHECK(hipEventRecord(c->ev[1], c->stream));
-    VkrBloomArgs b1 = bloom_args(c, f, 1);
-    if ((rc = vkr_bloom_blur(&b1, c->stream)) != VKR_OK) return rc;
     VKR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
-    // bloom pass 2 and the post-process draw run as one kernel; bloom-2 is not stored
-    VkrBloomPostArgs bp;
-    memset(&bp, 0, sizeof(bp));
-    bp.bloom1 = f.bloom1; bp.hdr = f.color; bp.out_rgba8 = f.ldr;
-    bp.width = c->cfg.width; bp.rows = c->cfg.height; bp.src_rows = c->cfg.height; bp.src_row_offset = 0;
-    bp.wrap = VKR_WRAP_CLAMP; bp.clamp_lo = 0; bp.clamp_hi = c->cfg.height - 1;
-    bp.flags = c->cfg.flags & VKR_POST_SRGB_TARGET;
-    if ((rc = vkr_bloomv_postprocess(&bp, c->stream)) != VKR_OK) return rc;
+    // both bloom passes and the post-process draw run as one kernel; neither bloom image is stored
+    VkrBloomChainArgs bc;
+    memset(&bc, 0, sizeof(bc));
+    bc.threshold = f.threshold; bc.hdr = f.color; bc.out_rgba8 = f.ldr;
+    bc.width = c->cfg.width; bc.rows = c->cfg.height; bc.src_rows = c->cfg.height; bc.src_row_offset = 0;
+    bc.wrap_h = VKR_WRAP_REPEAT; bc.clamp_lo_h = 0; bc.clamp_hi_h = c->cfg.width - 1;   // textureSampler along x
+    bc.wrap_v = VKR_WRAP_CLAMP; bc.clamp_lo_v = 0; bc.clamp_hi_v = c->cfg.height - 1;   // bloomSampler along y
+    bc.flags = c->cfg.flags & VKR_POST_SRGB_TARGET;
+    if ((rc = vkr_bloom_postprocess(&bc, c->stream)) != VKR_OK) return rc;
     VKR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
-    f.bloom2_valid = false;
+    f.bloom1_valid = f.bloom2_valid = false;
     c->timing_valid = true;
     c->in_frame = false;
     c->frame = (c->frame + 1) % c->cfg.frames_in_flight;  // VulkanRenderer.cs:622
@@ -747,7 +746,9 @@ extern "C" int32_t vkr_read(vkr_ctx *c, int32_t frame, int32_t target, int32_t m
         switch (target) {
         case VKR_TARGET_COLOR: src = f.color; bytes = img; break;
         case VKR_TARGET_THRESHOLD: src = f.threshold; bytes = img; break;
-        case VKR_TARGET_BLOOM1: src = f.bloom1; bytes = img; break;
+        case VKR_TARGET_BLOOM1:
+            if (!f.bloom1_valid) return fail(VKR_ERR_ORDER, "vkr_read: bloom-1 is only stored by vkr_pass_bloom(ctx, 1)");
+            src = f.bloom1; bytes = img; break;
         case VKR_TARGET_BLOOM2:
             if (!f.bloom2_valid) return fail(VKR_ERR_ORDER, "vkr_read: bloom-2 is only stored by vkr_pass_bloom(ctx, 0)");
             src = f.bloom2; bytes = img; break;

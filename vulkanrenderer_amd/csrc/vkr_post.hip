@@ -90,12 +90,15 @@ __global__ __launch_bounds__(256) void bloom_h_kernel(const BloomParams p)
     }
 }
 
-// postprocess.frag:11-18
+// postprocess.frag:11-18.  The argument is the sum of two binary16 values, so it is at most 131008 in magnitude,
+// infinite or NaN.  The denominator 2.43 c^2 + 0.59 c + 0.14 has no real root: for every finite argument it lies
+// in [0.104, 4.2e10], inside fast_rcp_rn's exact domain; an infinite or NaN argument gives NaN on the fast and on
+// the IEEE path alike, which the clamp turns into 0.
 VKR_DEV float aces(float c)
 {
     float num = c * fma_(2.51f, c, 0.03f);
-    float den = fma_(c, fma_(2.43f, c, 0.59f), 0.14f);  // >= 0.14 for c >= 0: inside fast_rcp_rn's exact domain
-    return clamp01(num * (c >= 0.0f ? fast_rcp_rn(den) : rcp_rn(den)));
+    float den = fma_(c, fma_(2.43f, c, 0.59f), 0.14f);
+    return clamp01(num * fast_rcp_rn(den));
 }
 
 // pow(m, 1/2.2) for m in [0,1] through the hardware log2/exp2 units
@@ -106,18 +109,21 @@ VKR_DEV float linear_to_srgb(float x)
     return x <= 0.0031308f ? 12.92f * x : fma_(1.055f, __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (1.0f / 2.4f)), -0.055f);
 }
 
+// One channel to its 8-bit code: floor(clamp(v) * 255 + 0.5).  The product is at least 0.5, so the conversion's
+// truncation is the floor.
+VKR_DEV uint32_t unorm8(float v) { return (uint32_t)fma_(clamp01(v), 255.0f, 0.5f); }
+
 VKR_DEV uint32_t tonemap_pack(float r, float g, float b, int flags)
 {
     float c[3] = {r, g, b};
-    uint32_t out = 0xFF000000u;
+    uint32_t q[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         float v = gamma22(aces(c[k]));
         if (flags & VKR_POST_SRGB_TARGET) v = linear_to_srgb(clamp01(v));
-        uint32_t q = (uint32_t)__builtin_floorf(fma_(clamp01(v), 255.0f, 0.5f));
-        out |= q << (8 * k);
+        q[k] = unorm8(v);
     }
-    return out;
+    return (q[0] | 0xFF000000u) | (q[1] << 8) | (q[2] << 16);
 }
 
 // Vertical pass, optionally fused with the post-process draw.  A workgroup owns 256 * PXL columns
@@ -205,6 +211,155 @@ __global__ __launch_bounds__(256) void bloom_v_kernel(const BloomParams p, const
     }
 }
 
+// Both bloom passes and the post-process draw in one kernel: 8 bytes of the thresholded image and 8 bytes of
+// the colour image in, 4 bytes out per pixel; neither bloom image is stored.  A workgroup is ONE wave that owns
+// 128 columns (two adjacent pixels per lane, 16-byte loads) and walks down `band` output rows.  Per source row
+// the wave stages its 136 texels (4-texel aprons) in LDS, every lane blurs its two pixels horizontally and
+// rounds them to binary16 -- the value the bloom-1 attachment would hold (bloom_blur.frag:14-33 through an
+// RGBA16F target) -- into a nine-row register window; the vertical blur, the rounding of the bloom-2 attachment,
+// the sum with the colour image and postprocess.frag:24-38 follow from registers.  Loads run BF_PF rows ahead of
+// their use.  With one wave per workgroup the LDS hand-over needs no barrier between waves.
+// The kernel is bound by VALU issue, not by memory (about 280 vector instructions per row step of 128 pixels:
+// 54 fmas for each blur, 13 per colour channel for ACES, gamma and the 8-bit code, conversions): what pays is
+// occupancy (four waves per SIMD: 43 us at 3840x2160 against 60 with three) and a row loop without per-lane
+// branches; a deeper load pipeline (BF_PF 3) costs registers and is slower.
+#ifndef VKR_BF_PF
+#define VKR_BF_PF 1
+#endif
+#ifndef VKR_BF_WAVES
+#define VKR_BF_WAVES 4
+#endif
+static constexpr int BF_COLS = 128, BF_PF = VKR_BF_PF;
+static_assert(9 % BF_PF == 0, "the prefetch slots rotate with the nine-row window");
+
+struct BloomFusedParams {
+    const uint2 *thr, *hdr; uint32_t *out8;
+    int width, rows, src_rows, src_row_offset;
+    int wrap_h, lo_h, hi_h, wrap_v, lo_v, hi_v;
+    int band;  // output rows per workgroup
+    int flags;
+};
+
+struct px2 { float r0, g0, b0, r1, g1, b1; };  // the two pixels of a lane
+
+// float(one binary16 half of `pair`) + float(b) in one mixed-precision fma: x * 1 + y is the correctly rounded sum,
+// and the two conversions to binary32 and the add (slow-class instructions, three of them) become one.
+template <int HI> VKR_DEV float add_half(uint32_t pair, _Float16 b)
+{
+    float o;
+    if (HI) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,1]" : "=v"(o) : "v"(pair), "v"(b));
+    else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(o) : "v"(pair), "v"(b));
+    return o;
+}
+
+// EVEN_REPEAT: the width is even and pass 1 wraps with REPEAT (the reference's state).  Every lane's pair of
+// columns is then an aligned 16-byte load, also where a tile reaches over the right edge (the pair wraps as a
+// pair), and the row loop has no per-lane branches.
+template <bool SRGB, bool EVEN_REPEAT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VKR_BF_WAVES, VKR_BF_WAVES))) void bloom_post_fused_kernel(const BloomFusedParams p)
+{
+    constexpr int flags = SRGB ? VKR_POST_SRGB_TARGET : 0;
+    __shared__ __align__(16) float tile[2][3][BF_COLS + 8];  // binary32 r, g, b planes of one source row, two rows in turn
+    const int t = threadIdx.x;
+    const int x0 = blockIdx.x * BF_COLS;
+    const int xa = x0 + 2 * t;
+    const int r0 = blockIdx.y * p.band;
+    const int nrows = min(p.band, p.rows - r0);
+    const bool inside = xa + 1 < p.width;
+    const bool vec = EVEN_REPEAT || ((p.width & 1) == 0 && inside);  // this lane's pair is a 16-byte aligned load
+    const int xw0 = wrap_index(xa, p.width, p.wrap_h, p.lo_h, p.hi_h), xw1 = wrap_index(xa + 1, p.width, p.wrap_h, p.lo_h, p.hi_h);
+    const int xh = EVEN_REPEAT ? min(xa, p.width - 2) : xa;  // colour-image column (lanes past the right edge load a valid pair and drop it)
+    const int apron_x = wrap_index(t < 4 ? x0 - 4 + t : x0 + BF_COLS + (t - 4), p.width, p.wrap_h, p.lo_h, p.hi_h);
+    const int apron_slot = t < 4 ? t : BF_COLS + 4 + (t - 4);
+
+    uint4 pf_body[BF_PF], pf_hdr[BF_PF];
+    uint2 pf_apron[BF_PF];
+    auto fetch = [&](int slot, int k) {  // source row k of the band (k = 0 is four rows above its first output row)
+        if (k < nrows + 8) {
+            int sr = wrap_index(r0 + k - 4 + p.src_row_offset, p.src_rows, p.wrap_v, p.lo_v, p.hi_v);
+            const uint2 *row = p.thr + (size_t)sr * p.width;
+            if (vec) pf_body[slot] = *reinterpret_cast<const uint4 *>(row + (EVEN_REPEAT ? xw0 : xa));
+            else { uint2 a = row[xw0], b = row[xw1]; pf_body[slot] = make_uint4(a.x, a.y, b.x, b.y); }
+            if (t < 8) pf_apron[slot] = row[apron_x];
+        }
+        int r = k - 8;  // the output row that source row completes
+        if (r >= 0 && r < nrows) {
+            const uint2 *row = p.hdr + (size_t)(r0 + r) * p.width;
+            if (vec) pf_hdr[slot] = *reinterpret_cast<const uint4 *>(row + xh);
+            else { uint2 a = row[min(xa, p.width - 1)], b = row[min(xa + 1, p.width - 1)]; pf_hdr[slot] = make_uint4(a.x, a.y, b.x, b.y); }
+        }
+    };
+    px2 win[9];  // the bloom-1 values (binary16) as binary32: a row is converted once, not once per output row it feeds
+    auto hblur = [&](int slot, int wslot, int k) {
+        // Every lane converts its own two texels (and eight lanes an apron texel) to binary32 and shares them
+        // through LDS: six conversions per lane and row instead of thirty, and a blur of full-rate fmas.
+        float (*buf)[BF_COLS + 8] = tile[k & 1];
+        const uint4 v = pf_body[slot];
+        const rgba lo = unpack4(make_uint2(v.x, v.y)), hi = unpack4(make_uint2(v.z, v.w));
+        *reinterpret_cast<float2 *>(&buf[0][4 + 2 * t]) = make_float2(lo.r, hi.r);
+        *reinterpret_cast<float2 *>(&buf[1][4 + 2 * t]) = make_float2(lo.g, hi.g);
+        *reinterpret_cast<float2 *>(&buf[2][4 + 2 * t]) = make_float2(lo.b, hi.b);
+        if (t < 8) {
+            const rgba a = unpack4(pf_apron[slot]);
+            buf[0][apron_slot] = a.r; buf[1][apron_slot] = a.g; buf[2][apron_slot] = a.b;
+        }
+        __syncthreads();
+        float c[3][10];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++)
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                const float2 f = *reinterpret_cast<const float2 *>(&buf[ch][2 * t + 2 * q]);
+                c[ch][2 * q] = f.x; c[ch][2 * q + 1] = f.y;
+            }
+        const float *r = c[0], *g = c[1], *b = c[2];
+        px2 o;
+        o.r0 = pin(round_f16(blur9(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8])));
+        o.g0 = pin(round_f16(blur9(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8])));
+        o.b0 = pin(round_f16(blur9(b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], b[8])));
+        o.r1 = pin(round_f16(blur9(r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9])));
+        o.g1 = pin(round_f16(blur9(g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[9])));
+        o.b1 = pin(round_f16(blur9(b[1], b[2], b[3], b[4], b[5], b[6], b[7], b[8], b[9])));
+        win[wslot] = o;
+    };
+
+#pragma unroll
+    for (int k = 0; k < BF_PF; k++) fetch(k, k);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {  // rows above the first output row
+        hblur(k % BF_PF, k, k);
+        fetch(k % BF_PF, k + BF_PF);
+    }
+    for (int rb = 0; rb < nrows; rb += 9) {
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+            const int r = rb + j, k = r + 8;
+            if (r >= nrows) return;
+            hblur((j + 8) % BF_PF, (j + 8) % 9, k);
+            const uint4 hv = pf_hdr[(j + 8) % BF_PF];
+            fetch((j + 8) % BF_PF, k + BF_PF);
+#define W_(ch, q) win[(j + (q)) % 9].ch
+            float br0 = blur9(W_(r0, 0), W_(r0, 1), W_(r0, 2), W_(r0, 3), W_(r0, 4), W_(r0, 5), W_(r0, 6), W_(r0, 7), W_(r0, 8));
+            float bg0 = blur9(W_(g0, 0), W_(g0, 1), W_(g0, 2), W_(g0, 3), W_(g0, 4), W_(g0, 5), W_(g0, 6), W_(g0, 7), W_(g0, 8));
+            float bb0 = blur9(W_(b0, 0), W_(b0, 1), W_(b0, 2), W_(b0, 3), W_(b0, 4), W_(b0, 5), W_(b0, 6), W_(b0, 7), W_(b0, 8));
+            float br1 = blur9(W_(r1, 0), W_(r1, 1), W_(r1, 2), W_(r1, 3), W_(r1, 4), W_(r1, 5), W_(r1, 6), W_(r1, 7), W_(r1, 8));
+            float bg1 = blur9(W_(g1, 0), W_(g1, 1), W_(g1, 2), W_(g1, 3), W_(g1, 4), W_(g1, 5), W_(g1, 6), W_(g1, 7), W_(g1, 8));
+            float bb1 = blur9(W_(b1, 0), W_(b1, 1), W_(b1, 2), W_(b1, 3), W_(b1, 4), W_(b1, 5), W_(b1, 6), W_(b1, 7), W_(b1, 8));
+#undef W_
+            // colour + bloom 2 (postprocess.frag:27-29), both read as binary16
+            uint32_t o0 = tonemap_pack(add_half<0>(hv.x, to_f16(br0)), add_half<1>(hv.x, to_f16(bg0)), add_half<0>(hv.y, to_f16(bb0)), flags);
+            uint32_t o1 = tonemap_pack(add_half<0>(hv.z, to_f16(br1)), add_half<1>(hv.z, to_f16(bg1)), add_half<0>(hv.w, to_f16(bb1)), flags);
+            uint32_t *orow = p.out8 + (size_t)(r0 + r) * p.width;
+            if (EVEN_REPEAT) { if (inside) *reinterpret_cast<uint2 *>(orow + xa) = make_uint2(o0, o1); }
+            else if (vec) *reinterpret_cast<uint2 *>(orow + xa) = make_uint2(o0, o1);
+            else {
+                if (xa < p.width) orow[xa] = o0;
+                if (xa + 1 < p.width) orow[xa + 1] = o1;
+            }
+        }
+    }
+}
+
 // Stand-alone post-process draw: two pixels per lane (16-byte loads, 8-byte store).
 __global__ __launch_bounds__(256) void postprocess_kernel(const uint4 *hdr, const uint4 *bloom, uint2 *out, size_t pairs, int flags)
 {
@@ -273,6 +428,41 @@ extern "C" int32_t vkr_bloomv_postprocess(const VkrBloomPostArgs *a, void *strea
     dim3 grid((a->width + 256 * PXL - 1) / (256 * PXL), (a->rows + VR - 1) / VR);
     hipLaunchKernelGGL(bloom_v_kernel<true>, grid, dim3(256), 0, as_stream(stream), p, (const uint2 *)a->hdr, (uint32_t *)a->out_rgba8, a->flags);
     return launch_status("vkr_bloomv_postprocess");
+}
+
+extern "C" int32_t vkr_bloom_postprocess(const VkrBloomChainArgs *a, void *stream)
+{
+    using namespace vkr;
+    VKR_REQUIRE(a != nullptr, "vkr_bloom_postprocess: args is null");
+    VKR_REQUIRE(a->threshold != nullptr && a->hdr != nullptr && a->out_rgba8 != nullptr, "vkr_bloom_postprocess: an image is null");
+    VKR_REQUIRE(a->width > 0 && a->rows > 0 && a->src_rows > 0, "vkr_bloom_postprocess: bad size %dx%d (src_rows %d)", a->width, a->rows, a->src_rows);
+    VKR_REQUIRE((a->wrap_h == VKR_WRAP_REPEAT || a->wrap_h == VKR_WRAP_CLAMP) && (a->wrap_v == VKR_WRAP_REPEAT || a->wrap_v == VKR_WRAP_CLAMP),
+                "vkr_bloom_postprocess: unknown wrap mode %d / %d", a->wrap_h, a->wrap_v);
+    if (a->wrap_h == VKR_WRAP_CLAMP)
+        VKR_REQUIRE(a->clamp_lo_h >= 0 && a->clamp_hi_h < a->width && a->clamp_lo_h <= a->clamp_hi_h,
+                    "vkr_bloom_postprocess: column clamp range [%d,%d] outside [0,%d)", a->clamp_lo_h, a->clamp_hi_h, a->width);
+    if (a->wrap_v == VKR_WRAP_CLAMP)
+        VKR_REQUIRE(a->clamp_lo_v >= 0 && a->clamp_hi_v < a->src_rows && a->clamp_lo_v <= a->clamp_hi_v,
+                    "vkr_bloom_postprocess: row clamp range [%d,%d] outside [0,%d)", a->clamp_lo_v, a->clamp_hi_v, a->src_rows);
+    BloomFusedParams p;
+    p.thr = (const uint2 *)a->threshold; p.hdr = (const uint2 *)a->hdr; p.out8 = (uint32_t *)a->out_rgba8;
+    p.width = a->width; p.rows = a->rows; p.src_rows = a->src_rows; p.src_row_offset = a->src_row_offset;
+    p.wrap_h = a->wrap_h; p.lo_h = a->clamp_lo_h; p.hi_h = a->clamp_hi_h;
+    p.wrap_v = a->wrap_v; p.lo_v = a->clamp_lo_v; p.hi_v = a->clamp_hi_v;
+    p.flags = a->flags;
+    // rows per wave: long bands blur fewer apron rows (8 per band), short ones give the chip more waves; aim at
+    // sixteen waves per CU (one round of four per SIMD) and stay between 16 rows (apron 50 %) and 32 (25 %)
+    const int tiles_x = (a->width + BF_COLS - 1) / BF_COLS;
+    long band = ((long)a->rows * tiles_x + 4095) / 4096;
+    static const int forced_band = getenv("VKR_BF_BAND") ? atoi(getenv("VKR_BF_BAND")) : 0;  // experiments
+    p.band = forced_band > 0 ? forced_band : (int)(band < 16 ? 16 : band > 32 ? 32 : band);
+    dim3 grid(tiles_x, (a->rows + p.band - 1) / p.band);
+    const bool srgb = (a->flags & VKR_POST_SRGB_TARGET) != 0;
+    const bool even_repeat = (a->width & 1) == 0 && a->wrap_h == VKR_WRAP_REPEAT;
+    auto kernel = srgb ? (even_repeat ? bloom_post_fused_kernel<true, true> : bloom_post_fused_kernel<true, false>)
+                       : (even_repeat ? bloom_post_fused_kernel<false, true> : bloom_post_fused_kernel<false, false>);
+    hipLaunchKernelGGL(kernel, grid, dim3(64), 0, as_stream(stream), p);
+    return launch_status("vkr_bloom_postprocess");
 }
 
 extern "C" int32_t vkr_postprocess(const void *hdr, const void *bloom, void *out_rgba8, int32_t width, int32_t rows, int32_t flags, void *stream)

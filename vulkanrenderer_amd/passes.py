@@ -264,6 +264,23 @@ def bloomv_postprocess(bloom1: torch.Tensor, hdr: torch.Tensor, out: torch.Tenso
     _lib.check(lib.vkr_bloomv_postprocess(C.byref(a), _stream()))
 
 
+def bloom_postprocess(threshold: torch.Tensor, hdr: torch.Tensor, out: torch.Tensor, flags: int = 0, *,
+                      src_row_offset: int = 0, wrap_h: int = _lib.WRAP_REPEAT, wrap_v: int = _lib.WRAP_CLAMP,
+                      clamp_h: tuple[int, int] | None = None, clamp_v: tuple[int, int] | None = None) -> None:
+    """Both bloom passes and the post-process draw in one kernel.  `threshold` may carry halo rows: output row r
+    is centred on its row r + src_row_offset; `clamp_v` is the valid range of its rows (default: all)."""
+    lib = _lib.load()
+    a = _lib.BloomChainArgs()
+    a.threshold, a.hdr, a.out_rgba8 = _ptr(threshold), _ptr(hdr), _ptr(out)
+    a.width, a.rows = hdr.shape[1], hdr.shape[0]
+    a.src_rows, a.src_row_offset = threshold.shape[0], src_row_offset
+    a.wrap_h, a.wrap_v = wrap_h, wrap_v
+    a.clamp_lo_h, a.clamp_hi_h = (0, a.width - 1) if clamp_h is None else clamp_h
+    a.clamp_lo_v, a.clamp_hi_v = (0, a.src_rows - 1) if clamp_v is None else clamp_v
+    a.flags = flags
+    _lib.check(lib.vkr_bloom_postprocess(C.byref(a), _stream()))
+
+
 def _rows(n_rows_total: int, rows: tuple[int, int] | None) -> tuple[int, int]:
     return (0, n_rows_total) if rows is None else rows
 

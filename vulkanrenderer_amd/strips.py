@@ -3,10 +3,11 @@
 The reference renders on one device; nothing in it partitions a frame.  The shading path shards
 naturally by rows: the composition pass and the post-process draw are per-pixel, bloom pass 1
 (horizontal, REPEAT) is per-row, and bloom pass 2 (vertical, CLAMP_TO_EDGE) reads 4 rows above and
-below each output row.  So each rank shades its strip, blurs it horizontally, swaps 4 boundary rows
-of the pass-1 image with its neighbours (point-to-point over RCCL / xGMI, or gloo on CPU), and
-finishes with the fused vertical-blur + tonemap kernel.  There is no reduction anywhere, so the
-assembled image is bit-identical to a single-GPU run.
+below each output row.  So each rank shades its strip, swaps 4 boundary rows of the thresholded
+image (the source of bloom pass 1) with its neighbours (point-to-point over RCCL / xGMI, or gloo on
+CPU), and finishes with the one kernel that runs both bloom passes and the tonemap: a rank blurs the
+neighbours' four rows horizontally itself, which costs less than storing and re-reading a pass-1
+image.  There is no reduction anywhere, so the assembled image is bit-identical to a single-GPU run.
 
 Scene constants, lights, shadow maps and IBL images are replicated; only the G-buffer is split.
 """
@@ -97,14 +98,10 @@ class HipBackend:
         verts, tris = volume_mesh
         return dataclasses.replace(frame, coverage=self.P.light_coverage(frame, verts, tris, frame_rows, row0))
 
-    def bloom_h(self, thr, bloom1, rows, y0=0, y1=None):
-        # writes rows [HALO + y0, HALO + y1) of the halo-padded pass-1 image (the whole strip by default)
-        y1 = rows if y1 is None else y1
-        self.P.bloom_blur(thr[y0:y1], bloom1[HALO + y0:HALO + y1], True, _lib.WRAP_REPEAT, rows=y1 - y0)
-
-    def bloomv_post(self, bloom1, hdr, out, lo, hi, row0=0):
-        # output row k of `hdr`/`out` is strip row row0 + k, centred on row HALO + row0 + k of bloom1
-        self.P.bloomv_postprocess(bloom1, hdr, out, 0, src_row_offset=HALO + row0, clamp_lo=lo, clamp_hi=hi)
+    def bloom_post(self, thr, hdr, out, lo, hi, row0=0):
+        # `thr` is the halo-padded thresholded image; output row k of `hdr`/`out` is strip row row0 + k, centred
+        # on row HALO + row0 + k of `thr`; vertical taps clamp to rows [lo, hi] of `thr`
+        self.P.bloom_postprocess(thr, hdr, out, 0, src_row_offset=HALO + row0, clamp_v=(lo, hi))
 
 
 class StripRenderer:
@@ -117,8 +114,9 @@ class StripRenderer:
         self.backend = backend if backend is not None else HipBackend(device)
         r = plan.rows
         self.color = self.backend.empty((r, width, 4), torch.float16)
-        self.threshold = self.backend.empty((r, width, 4), torch.float16)
-        self.bloom1 = self.backend.empty((r + 2 * HALO, width, 4), torch.float16)
+        # the thresholded image with HALO rows of each neighbour above and below the strip's own rows
+        self.threshold_padded = self.backend.empty((r + 2 * HALO, width, 4), torch.float16)
+        self.threshold = self.threshold_padded[HALO:HALO + r]
         self._ring = [self.backend.empty((r, width, 4), torch.uint8) for _ in range(max(frames_in_flight, 1))]
         self._slot = 0
         self.ldr = self._ring[0]
@@ -129,18 +127,18 @@ class StripRenderer:
         self.marks = None  # a list: render() and gather() append (phase name, event recorded when the phase's work ends)
 
     def start_halo_exchange(self) -> list:
-        """Rows HALO..2*HALO go to the rank above, the last HALO real rows to the rank below.
-        Returns the pending requests (empty on a single rank)."""
-        p, r = self.plan, self.plan.rows
+        """The first HALO rows of the strip's thresholded image go to the rank above, the last HALO to the rank
+        below.  Returns the pending requests (empty on a single rank)."""
+        p, r, t = self.plan, self.plan.rows, self.threshold_padded
         if p.world == 1:
             return []
         ops = []
         if not p.is_top:
-            ops.append(dist.P2POp(dist.isend, self.bloom1[HALO:2 * HALO], p.rank - 1, self.group))
-            ops.append(dist.P2POp(dist.irecv, self.bloom1[0:HALO], p.rank - 1, self.group))
+            ops.append(dist.P2POp(dist.isend, t[HALO:2 * HALO], p.rank - 1, self.group))
+            ops.append(dist.P2POp(dist.irecv, t[0:HALO], p.rank - 1, self.group))
         if not p.is_bottom:
-            ops.append(dist.P2POp(dist.isend, self.bloom1[r:r + HALO], p.rank + 1, self.group))
-            ops.append(dist.P2POp(dist.irecv, self.bloom1[r + HALO:r + 2 * HALO], p.rank + 1, self.group))
+            ops.append(dist.P2POp(dist.isend, t[r:r + HALO], p.rank + 1, self.group))
+            ops.append(dist.P2POp(dist.irecv, t[r + HALO:r + 2 * HALO], p.rank + 1, self.group))
         return dist.batch_isend_irecv(ops)
 
     def exchange_halo(self) -> None:
@@ -163,9 +161,9 @@ class StripRenderer:
             self.marks.append((name, ev))
 
     def render(self, frame, volume_mesh=None) -> torch.Tensor:
-        """composition and bloom 1 of the rows next to a neighbour -> halo exchange, overlapped with
-        composition and bloom 1 of all other rows and the interior rows of bloom 2 + post-process ->
-        the rows next to a neighbour; returns the RGBA8 strip.  With `volume_mesh`
+        """composition of the rows next to a neighbour -> halo exchange of their thresholded rows, overlapped
+        with the composition of all other rows and the bloom + post-process kernel over the rows that reach no
+        halo row -> the rows next to a neighbour; returns the RGBA8 strip.  With `volume_mesh`
         each light's draw is limited to the pixels its volume covers; the strip's place in the
         frame (plan.row0 of plan.total_rows) enters the projection, nothing is exchanged for it."""
         p, r = self.plan, self.plan.rows
@@ -182,32 +180,30 @@ class StripRenderer:
         # rows [top, bottom) reach no halo row: they run while the halo rows are in flight
         top = 0 if p.is_top else HALO
         bottom = r if p.is_bottom else r - HALO
-        # The rows a neighbour needs are shaded and blurred first (bands of whole 8-row tiles), so that the
-        # halo exchange is in flight during the shading of everything else, the long part of a frame.
+        # The rows a neighbour needs are shaded first (bands of whole 8-row tiles), so that the halo exchange is
+        # in flight during the shading of everything else, the long part of a frame.
         a = 0 if p.is_top else min(8, r)
         b = r if p.is_bottom else max(((r - HALO) // 8) * 8, a)
         self._mark("frame_start")
         for y0, y1 in ((0, a), (b, r)):
             if y1 > y0:
                 be.shade(frame, self.color, self.threshold, y0, y1)
-                be.bloom_h(self.threshold, self.bloom1, r, y0, y1)
-        self._mark("edge_bands_shade_bloomh")
+        self._mark("edge_bands_shade")
         pending = self.start_halo_exchange()
         if b > a:
             be.shade(frame, self.color, self.threshold, a, b)
-            be.bloom_h(self.threshold, self.bloom1, r, a, b)
-        self._mark("interior_shade_bloomh")
+        self._mark("interior_shade")
         if bottom > top:
-            be.bloomv_post(self.bloom1, self.color[top:bottom], self.ldr[top:bottom], lo, hi, row0=top)
-        self._mark("interior_bloomv_post")
+            be.bloom_post(self.threshold_padded, self.color[top:bottom], self.ldr[top:bottom], lo, hi, row0=top)
+        self._mark("interior_bloom_post")
         for req in pending:
             req.wait()
         self._mark("halo_wait")  # what of the exchange the interior work did not hide
         if top > 0:
-            be.bloomv_post(self.bloom1, self.color[:top], self.ldr[:top], lo, hi, row0=0)
+            be.bloom_post(self.threshold_padded, self.color[:top], self.ldr[:top], lo, hi, row0=0)
         if bottom < r:
-            be.bloomv_post(self.bloom1, self.color[max(bottom, top):], self.ldr[max(bottom, top):], lo, hi, row0=max(bottom, top))
-        self._mark("edge_bloomv_post")
+            be.bloom_post(self.threshold_padded, self.color[max(bottom, top):], self.ldr[max(bottom, top):], lo, hi, row0=max(bottom, top))
+        self._mark("edge_bloom_post")
         return self.ldr
 
     def gather(self, dst: int = 0):
