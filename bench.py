@@ -393,8 +393,10 @@ def time_coverage(f, dev_frame, renderer, device) -> dict:
     verts, tris = synth.make_sphere_mesh()
     dverts, dtris = torch.from_numpy(verts).to(device), torch.from_numpy(tris.astype(np.int32)).to(device)
 
-    def timed(fn, reps=5):
-        fn(); torch.cuda.synchronize()
+    def timed(fn, reps=10):
+        for _ in range(3):  # clocks and caches settle over the first launches of a different kernel
+            fn()
+        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
@@ -404,12 +406,21 @@ def time_coverage(f, dev_frame, renderer, device) -> dict:
 
     out = {}
     want = renderer.color.clone()
-    masked = dataclasses.replace(dev_frame, coverage=P.light_coverage(dev_frame, dverts, dtris))
+    masks, flags = P.light_coverage_with_flags(dev_frame, dverts, dtris)
+    masked = dataclasses.replace(dev_frame, coverage=masks, coverage_flags=flags)
     color, thr = torch.empty_like(renderer.color), torch.empty_like(renderer.threshold)
-    out["reference_radii"] = {"coverage_ms": round(timed(lambda: P.light_coverage(dev_frame, dverts, dtris)), 4),
+    out["reference_radii"] = {"coverage_ms": round(timed(lambda: P.light_coverage_with_flags(dev_frame, dverts, dtris)), 4),
                               "shade_ms": round(timed(lambda: P.shade(masked, color, thr)), 4),
+                              "lights_flagged_as_covering_every_pixel": int(flags[:-1].sum()), "lights": int(flags.numel() - 1),
                               "covered_fraction": 1.0 if bool((masked.coverage == -1).all()) else None,
-                              "equals_full_coverage_image": bool(torch.equal(color, want))}
+                              "equals_full_coverage_image": bool(torch.equal(color, want)),
+                              "note": "the camera is inside every volume: the classification kernel says so per light, the masks are "
+                                      "written as all ones without rasterising, and the shading kernel takes its loop without masks"}
+    unflagged = dataclasses.replace(dev_frame, coverage=P.light_coverage(dev_frame, dverts, dtris))
+    out["reference_radii_rasterised"] = {"coverage_ms": round(timed(lambda: P.light_coverage(dev_frame, dverts, dtris)), 4),
+                                         "shade_ms": round(timed(lambda: P.shade(unflagged, color, thr)), 4),
+                                         "masks_equal": bool(torch.equal(unflagged.coverage, masks)),
+                                         "note": "the same lights without the per-light words: every volume rasterised, every mask read"}
     lights = f.lights.copy()
     for i in range(len(lights)):
         lights["color"][i] *= 0.02
@@ -417,10 +428,10 @@ def time_coverage(f, dev_frame, renderer, device) -> dict:
         m = np.diag([r, r, r, 1.0]); m[3, :3] = lights["position"][i]
         lights["model"][i] = m.astype(np.float32).ravel()
     small = dataclasses.replace(dev_frame, lights=torch.from_numpy(np.frombuffer(lights.tobytes(), dtype=np.uint8).copy()).to(device))
-    small.coverage = P.light_coverage(small, dverts, dtris)
+    small.coverage, small.coverage_flags = P.light_coverage_with_flags(small, dverts, dtris)
     bits = small.coverage.view(torch.uint8)
     frac = float(sum(int(((bits >> k) & 1).sum()) for k in range(8))) / (len(lights) * f.width * f.height)
-    out["local_lights"] = {"coverage_ms": round(timed(lambda: P.light_coverage(small, dverts, dtris)), 4),
+    out["local_lights"] = {"coverage_ms": round(timed(lambda: P.light_coverage_with_flags(small, dverts, dtris)), 4),
                            "shade_ms": round(timed(lambda: P.shade(small, color, thr)), 4),
                            "covered_fraction": round(frac, 4),
                            "note": "same lights with colours x0.02: volume radius 16*sqrt(max/5) shrinks to ~1-2.5 units"}

@@ -124,6 +124,9 @@ typedef struct VkrShadeArgs {
     const void *prefilter;    int32_t pref_res;   /* RGBA16F cube (mip 0) */
     const void *brdf_lut;     int32_t lut_res;    /* RG16F */
     void *out_color, *out_threshold;              /* RGBA16F, rows*width texels each */
+    const uint32_t *coverage_flags;               /* VKR_COVERAGE_MESH: VkrCoverageArgs.light_flags of the call that wrote
+                                                     coverage_masks, or NULL; when it says that every light covers every
+                                                     pixel the masks are not read */
 } VkrShadeArgs;
 VKR_EXPORT int32_t vkr_shade(const VkrShadeArgs *args, void *stream);
 
@@ -144,6 +147,11 @@ typedef struct VkrCoverageArgs {
     const uint32_t *indices;      /* device memory, 3 per triangle, counter-clockwise seen from outside */
     int32_t n_tris;
     uint64_t *masks;              /* device memory, n_lights * ceil(rows/8) * ceil(width/8) */
+    uint32_t *light_flags;        /* device memory, n_lights + 1 words, or NULL.  Word i becomes 1 when light i's volume
+                                     provably covers every pixel (the camera sees every triangle of the closed mesh from
+                                     behind and every triangle a pixel ray can hit lies between the near and the far
+                                     plane): such a light's masks are written as all ones without rasterising anything.
+                                     Word n_lights becomes the number of lights whose word is 0. */
 } VkrCoverageArgs;
 VKR_EXPORT int32_t vkr_light_coverage(const VkrCoverageArgs *args, void *stream);
 

@@ -1,15 +1,36 @@
-"""Profiling helper: builds the benchmark frame and runs only the shade kernel a few times."""
-import os, sys
+"""Times the shading kernel alone on the benchmark frame (HIP events): without masks, with the masks and per-light
+words of the coverage pass (reference radii: every light covers every pixel), and with the masks alone.
+VKR_HIP_LIB selects a library build; VKR_LIGHTS the number of lights; VKR_ONLY=plain|flags|masks runs one form
+(for counter passes)."""
+import dataclasses, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
 import torch
 import bench
-from vulkanrenderer_amd import passes as P
+from vulkanrenderer_amd import passes as P, synth
 dev = torch.device("cuda", 0)
 L = int(os.environ.get("VKR_LIGHTS", "64"))
-f, d = bench.build_inputs(0, dev, bench.HEIGHT, L, bench.CUBE_RES, bench.DIR_RES)
+scene = bench.build_scene(dev, L, bench.CUBE_RES, bench.DIR_RES)
+f = bench.frame_of(scene, synth.make_gbuffer(np.random.default_rng(bench.SEED + 1000), bench.WIDTH, bench.HEIGHT), bench.WIDTH, bench.HEIGHT)
+d = P.DeviceFrame.upload(f, dev)
 color = torch.empty((bench.HEIGHT, bench.WIDTH, 4), dtype=torch.float16, device=dev)
 thr = torch.empty_like(color)
-for _ in range(int(os.environ.get("VKR_REPS", "3"))):
-    P.shade(d, color, thr)
-torch.cuda.synchronize()
-print("done")
+verts, tris = synth.make_sphere_mesh()
+dverts, dtris = torch.from_numpy(verts).to(dev), torch.from_numpy(tris.astype(np.int32)).to(dev)
+masks, flags = P.light_coverage_with_flags(d, dverts, dtris)
+forms = {"plain": d, "flags": dataclasses.replace(d, coverage=masks, coverage_flags=flags), "masks": dataclasses.replace(d, coverage=masks)}
+only = os.environ.get("VKR_ONLY")
+reps = int(os.environ.get("VKR_REPS", "10"))
+res = {n: [] for n in forms}
+for rnd in range(int(os.environ.get("VKR_ROUNDS", "4"))):  # interleaved: clocks settle over the first launches
+    for name, fr in forms.items():
+        if only and name != only:
+            continue
+        P.shade(fr, color, thr); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            P.shade(fr, color, thr)
+        e1.record(); torch.cuda.synchronize()
+        res[name].append(round(e0.elapsed_time(e1) / reps, 3))
+print(os.environ.get("VKR_HIP_LIB", "default"), res, flush=True)

@@ -464,6 +464,11 @@ def _camera_scene(cam, target=(0.0, 0.0, 0.0), aspect=16.0 / 9.0):
     return s
 
 
+def _toward_origin(cam):
+    d = -np.array(cam, dtype=np.float64)
+    return d / np.linalg.norm(d)
+
+
 def _small_lights(rng, n, scale):
     """Lights whose volumes are much smaller than the reference's (colour maximum `scale` * U[0.2,1])."""
     lights = synth.make_lights(rng, n)
@@ -499,6 +504,79 @@ def test_light_coverage_masks_bit_exact(gpu, oracle, w, h, row0, frame_rows):
     got = got.cpu().numpy().view(np.uint64)
     assert got.shape == want.shape
     assert np.array_equal(got, want), f"{(got != want).sum()} of {got.size} tile masks differ"
+
+
+@pytest.mark.parametrize("w,h,row0,frame_rows", [(200, 120, 0, 120), (203, 61, 40, 120)])
+def test_light_coverage_flags_name_only_lights_that_cover_every_pixel(gpu, oracle, w, h, row0, frame_rows):
+    """The per-light words of vkr_light_coverage: set for volumes that hold the camera well inside, clear for a
+    camera outside, near the surface, for a volume cut by the far plane and for one the near plane cuts inside the
+    view; wherever a word is set the oracle's rasterisation has every pixel covered, and the masks written with the
+    words equal the oracle's bit for bit (ragged widths and a strip included: bits beyond the image stay clear)."""
+    torch, P = _torch(), _passes()
+    verts, tris = synth.make_sphere_mesh()
+    cam = (2.0, 1.0, -4.0)
+    cases = [(cam, 8.0),                      # camera at the centre
+             ((3.0, 2.0, -2.0), 12.0),        # camera well inside
+             (tuple(np.array(cam) - 7.95 * _toward_origin(cam)), 8.0),   # camera inside, the surface 0.05 ahead of it: the near plane (0.1) cuts the volume in view
+             ((2.0, 1.0, 8.0), 3.0),          # camera outside
+             ((2.0, 1.0, 40.0), 70.0),        # reaches beyond the far plane (100)
+             ((2.5, 1.0, -4.0), 0.45),        # camera outside a small volume beside it
+             ((2.0, 1.0, -4.02), 0.05)]       # camera inside a volume smaller than the near plane distance (0.1)
+    nl = len(cases)
+    f = synth.make_frame(63, w, h, nl, 16, 64, irr_res=8, pref_res=16, lut_res=32)
+    f.scene = _camera_scene(cam, aspect=w / frame_rows)
+    for i, (pos, r) in enumerate(cases):
+        m = np.diag([r, r, r, 1.0]); m[3, :3] = pos
+        f.lights["model"][i] = m.astype(np.float32).ravel()
+        f.lights["position"][i] = pos
+    want = oracle.light_coverage(f.scene, f.lights, verts, tris, w, h, frame_rows, row0)
+    full = oracle.coverage_to_image(want, w, h).reshape(nl, -1).all(axis=1)
+    d = P.DeviceFrame.upload(f, gpu)
+    got, flags = P.light_coverage_with_flags(d, torch.from_numpy(verts).to(gpu), torch.from_numpy(tris.astype(np.int32)).to(gpu), frame_rows, row0)
+    flags = flags.cpu().numpy()
+    assert np.array_equal(got.cpu().numpy().view(np.uint64), want), "masks written with the flags differ from the oracle's"
+    assert flags[0] == 1 and flags[1] == 1, flags
+    assert not flags[2:nl].any(), flags
+    assert flags[nl] == nl - int(flags[:nl].sum())
+    assert all(full[i] for i in range(nl) if flags[i]), "a flagged light leaves a pixel uncovered"
+    assert not full[2] and not full[6]  # the near plane clips what the camera sees of these two
+
+
+def test_shade_skips_the_masks_when_every_light_covers_every_pixel(gpu, oracle):
+    """With the reference's light radii and the camera inside every volume the words say so, the masks are all
+    ones, and the shaded images equal the ones shaded without masks, whether or not the words are passed on."""
+    torch, P = _torch(), _passes()
+    w, h, nl = 176, 104, 7
+    verts, tris = synth.make_sphere_mesh()
+    dverts, dtris = torch.from_numpy(verts).to(gpu), torch.from_numpy(tris.astype(np.int32)).to(gpu)
+    f = synth.make_frame(62, w, h, nl, 32, 128, irr_res=8, pref_res=16, lut_res=32)
+    f.scene = _camera_scene((2.0, 1.0, -4.0), aspect=w / h)
+    color, thr = torch.empty((h, w, 4), dtype=torch.float16, device=gpu), torch.empty((h, w, 4), dtype=torch.float16, device=gpu)
+    d = P.DeviceFrame.upload(f, gpu)
+    P.shade(d, color, thr)
+    full_c, full_t = P.f16_bits(color).copy(), P.f16_bits(thr).copy()
+    d.coverage, d.coverage_flags = P.light_coverage_with_flags(d, dverts, dtris)
+    assert d.coverage_flags.cpu().tolist() == [1] * nl + [0]
+    assert bool((d.coverage == -1).all())
+    for with_flags in (True, False):
+        if not with_flags:
+            d.coverage_flags = None
+        color.zero_(); thr.zero_()
+        P.shade(d, color, thr)
+        assert np.array_equal(P.f16_bits(color), full_c) and np.array_equal(P.f16_bits(thr), full_t)
+    # one local light among them: the count is 1 and the masked loop runs (bit-exact against the oracle with the same masks)
+    f.lights["color"][3] *= 0.004
+    r = synth.light_volume_radius(f.lights["color"][3])
+    m = np.diag([r, r, r, 1.0]); m[3, :3] = f.lights["position"][3]
+    f.lights["model"][3] = m.astype(np.float32).ravel()
+    d = P.DeviceFrame.upload(f, gpu)
+    d.coverage, d.coverage_flags = P.light_coverage_with_flags(d, dverts, dtris)
+    assert int(d.coverage_flags[nl]) == 1 and int(d.coverage_flags[3]) == 0
+    masks = oracle.light_coverage(f.scene, f.lights, verts, tris, w, h)
+    assert np.array_equal(d.coverage.cpu().numpy().view(np.uint64), masks)
+    P.shade(d, color, thr)
+    want_c, want_t = oracle.shade(f, coverage=masks)
+    assert np.array_equal(P.f16_bits(color), want_c) and np.array_equal(P.f16_bits(thr), want_t)
 
 
 def test_shade_with_light_volume_coverage(gpu, oracle):

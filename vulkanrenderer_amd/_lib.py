@@ -60,7 +60,7 @@ class ShadeArgs(C.Structure):
                 ("irradiance", C.c_void_p), ("irr_res", C.c_int32),
                 ("prefilter", C.c_void_p), ("pref_res", C.c_int32),
                 ("brdf_lut", C.c_void_p), ("lut_res", C.c_int32),
-                ("out_color", C.c_void_p), ("out_threshold", C.c_void_p)]
+                ("out_color", C.c_void_p), ("out_threshold", C.c_void_p), ("coverage_flags", C.c_void_p)]
 
 
 class CoverageArgs(C.Structure):
@@ -69,7 +69,7 @@ class CoverageArgs(C.Structure):
                 ("lights", C.c_void_p), ("n_lights", C.c_int32),
                 ("verts", C.c_void_p), ("n_verts", C.c_int32),
                 ("indices", C.c_void_p), ("n_tris", C.c_int32),
-                ("masks", C.c_void_p)]
+                ("masks", C.c_void_p), ("light_flags", C.c_void_p)]
 
 
 class MeshDraw(C.Structure):

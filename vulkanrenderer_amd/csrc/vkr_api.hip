@@ -93,7 +93,8 @@ static int32_t alloc_frame_sized(vkr_ctx *c)
         VKR_HIP_CHECK(hipMalloc(&f.bloom2, img));
         VKR_HIP_CHECK(hipMalloc(&f.ldr, (size_t)c->cfg.width * c->cfg.height * 4));
         const size_t tiles = (size_t)((c->cfg.width + 7) / 8) * ((c->cfg.height + 7) / 8);
-        VKR_HIP_CHECK(hipMalloc((void **)&f.coverage_buf, (size_t)c->cfg.max_lights * tiles * sizeof(uint64_t)));
+        // the masks, then the per-light words of VkrCoverageArgs.light_flags (max_lights + 1, rounded up to whole masks)
+        VKR_HIP_CHECK(hipMalloc((void **)&f.coverage_buf, ((size_t)c->cfg.max_lights * tiles + (size_t)c->cfg.max_lights / 2 + 1) * sizeof(uint64_t)));
     }
     return VKR_OK;
 }
@@ -164,6 +165,13 @@ static void destroy(vkr_ctx *c)
     delete c;
 }
 
+// the per-light words of VkrCoverageArgs.light_flags live behind the masks
+static uint32_t *coverage_flags(vkr_ctx *c, Frame &f)
+{
+    const size_t tiles = (size_t)((c->cfg.width + 7) / 8) * ((c->cfg.height + 7) / 8);
+    return (uint32_t *)(f.coverage_buf + (size_t)c->cfg.max_lights * tiles);
+}
+
 static int32_t run_coverage(vkr_ctx *c, Frame &f);
 static int32_t run_shadow_passes(vkr_ctx *c, Frame &f);
 static int32_t run_geometry_pass(vkr_ctx *c, Frame &f);
@@ -198,6 +206,7 @@ static int32_t fill_shade_args(vkr_ctx *c, Frame &f, VkrShadeArgs &a)
     a.brdf_lut = c->brdf_lut; a.lut_res = c->cfg.brdf_lut_res;
     a.out_color = f.color; a.out_threshold = f.threshold;
     a.coverage_masks = f.coverage == VKR_COVERAGE_MESH ? f.coverage_buf : nullptr;
+    a.coverage_flags = f.coverage == VKR_COVERAGE_MESH ? coverage_flags(c, f) : nullptr;
     return VKR_OK;
 }
 
@@ -277,6 +286,7 @@ static int32_t run_coverage(vkr_ctx *c, Frame &f)
     a.verts = c->mesh_verts; a.n_verts = c->mesh_n_verts;
     a.indices = c->mesh_indices; a.n_tris = c->mesh_n_tris;
     a.masks = f.coverage_buf;
+    a.light_flags = coverage_flags(c, f);
     return vkr_light_coverage(&a, c->stream);
 }
 

@@ -29,9 +29,11 @@ struct CoverageParams {
     int width, rows, frame_rows, row0;
     float view[16], proj[16];
     const float *lights;  // VkrLightInfo array viewed as floats, 23 per light
+    int n_lights;
     const float *verts; int n_verts;
     const unsigned *indices; int n_tris;
     unsigned long long *masks;
+    unsigned *flags;  // per light: 1 = covers every pixel (coverage_classify_kernel); or null
     int tiles_x, tiles_y, blocks_x;
 };
 
@@ -39,19 +41,11 @@ struct CovTri { double a[3], b[3], c[3], z[3], D; };
 
 VKR_DEV double cov_edge(const CovTri &t, int i, double xn, double yn) { return __builtin_fma(t.a[i], xn, __builtin_fma(t.b[i], yn, t.c[i])); }
 
-__global__ __launch_bounds__(256) void coverage_kernel(const CoverageParams p)
+// light.vert:26 for every vertex of the volume mesh of light `li`, evaluated left to right: (proj * view) * model,
+// row-vector convention.  Called by all 256 threads of a workgroup; the clip-space vertices are in LDS when it returns.
+VKR_DEV void transform_volume(const CoverageParams &p, int li, float *s_vp, float *s_mvp, float4 *s_clip)
 {
-    __shared__ float s_vp[16], s_mvp[16];
-    __shared__ float4 s_clip[COV_MAX_VERTS];
-    __shared__ CovTri s_tri[256];
-    __shared__ int s_count;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = blockIdx.y;
-    const int bx0 = (blockIdx.x % p.blocks_x) * COV_BLOCK, by0 = (blockIdx.x / p.blocks_x) * COV_BLOCK;
-    const int bx1 = min(bx0 + COV_BLOCK, p.width), by1 = min(by0 + COV_BLOCK, p.rows);
-
-    // light.vert:26 evaluated left to right: (proj * view) * model, row-vector convention
+    const int tid = threadIdx.x;
     const float *model = p.lights + (size_t)li * 23;
     if (tid < 16) {
         const int i = tid >> 2, j = tid & 3;
@@ -71,6 +65,89 @@ __global__ __launch_bounds__(256) void coverage_kernel(const CoverageParams p)
         s_clip[v] = make_float4(o[0], o[1], o[2], o[3]);
     }
     __syncthreads();
+}
+
+// Edge functions and the back-face determinant of one triangle from its clip-space corners.
+VKR_DEV void cov_setup(const float4 &c0, const float4 &c1, const float4 &c2, CovTri &tr)
+{
+    const double x0 = c0.x, y0 = c0.y, w0 = c0.w, x1 = c1.x, y1 = c1.y, w1 = c1.w, x2 = c2.x, y2 = c2.y, w2 = c2.w;
+    tr.a[0] = y1 * w2 - w1 * y2; tr.b[0] = w1 * x2 - x1 * w2; tr.c[0] = x1 * y2 - y1 * x2;
+    tr.a[1] = y2 * w0 - w2 * y0; tr.b[1] = w2 * x0 - x2 * w0; tr.c[1] = x2 * y0 - y2 * x0;
+    tr.a[2] = y0 * w1 - w0 * y1; tr.b[2] = w0 * x1 - x0 * w1; tr.c[2] = x0 * y1 - y0 * x1;
+    tr.z[0] = c0.z; tr.z[1] = c1.z; tr.z[2] = c2.z;
+    tr.D = __builtin_fma(w0, tr.c[0], __builtin_fma(y0, tr.b[0], x0 * tr.a[0]));
+}
+
+// Does light blockIdx.x cover every pixel?  Sufficient conditions, decided on the very clip-space vertices and
+// determinants the rasterising kernel works with:
+//  (1) every triangle with an area is seen from behind (D > 0): the camera lies inside the closed mesh, on the inner
+//      side of every face, so every view ray leaves the mesh through exactly one triangle, and that triangle is one
+//      the draw keeps (FRONT faces culled);
+//  (2) every triangle is either in front of the near plane with all three corners (z >= 0, w > 0), or cannot be hit by
+//      the ray of any pixel (all corners outside one side plane of the view volume, or all behind the eye): the
+//      triangle a ray leaves through passes the z >= 0 half of the depth clip (a sum of non-negative products);
+//  (3) every vertex is on the near side of the far plane by a relative margin of 1e-6, nine orders of magnitude above the
+//      rounding of the binary64 depth test: the z <= w half passes.
+// A triangle with two equal corners has no area: it touches no pixel and bounds no hole.  Anything else (a camera
+// outside or on the mesh, a volume that reaches the far plane, a triangle that straddles the near plane inside the
+// view volume) leaves the flag at 0 and the light is rasterised.
+__global__ __launch_bounds__(256) void coverage_classify_kernel(const CoverageParams p)
+{
+    __shared__ float s_vp[16], s_mvp[16];
+    __shared__ float4 s_clip[COV_MAX_VERTS];
+    const int tid = threadIdx.x, li = blockIdx.x;
+    transform_volume(p, li, s_vp, s_mvp, s_clip);
+    bool bad = false;
+    for (int v = tid; v < p.n_verts; v += 256) {
+        const float4 c = s_clip[v];
+        bad = bad || !(c.w - c.z > 1e-6f * fmaxf(fabsf(c.w), fabsf(c.z)));  // also catches NaN
+    }
+    const unsigned vmax = (unsigned)p.n_verts - 1u;
+    for (int t = tid; t < p.n_tris; t += 256) {
+        const float4 c0 = s_clip[min(p.indices[3 * t], vmax)], c1 = s_clip[min(p.indices[3 * t + 1], vmax)], c2 = s_clip[min(p.indices[3 * t + 2], vmax)];
+        auto same = [](const float4 &a, const float4 &b) { return a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w; };
+        if (same(c0, c1) || same(c1, c2) || same(c2, c0)) continue;
+        CovTri tr;
+        cov_setup(c0, c1, c2, tr);
+        const bool in_front = c0.z >= 0.0f && c1.z >= 0.0f && c2.z >= 0.0f && c0.w > 0.0f && c1.w > 0.0f && c2.w > 0.0f;
+        const bool unseen = (c0.x > c0.w && c1.x > c1.w && c2.x > c2.w) || (c0.x < -c0.w && c1.x < -c1.w && c2.x < -c2.w) ||
+                            (c0.y > c0.w && c1.y > c1.w && c2.y > c2.w) || (c0.y < -c0.w && c1.y < -c1.w && c2.y < -c2.w) ||
+                            (c0.w < 0.0f && c1.w < 0.0f && c2.w < 0.0f);
+        bad = bad || !(tr.D > 0.0) || !(in_front || unseen);
+    }
+    const int any_bad = __syncthreads_or(bad ? 1 : 0);
+    if (tid == 0) {
+        p.flags[li] = any_bad ? 0u : 1u;
+        if (any_bad) atomicAdd(&p.flags[p.n_lights], 1u);
+    }
+}
+
+__global__ __launch_bounds__(256) void coverage_kernel(const CoverageParams p)
+{
+    __shared__ float s_vp[16], s_mvp[16];
+    __shared__ float4 s_clip[COV_MAX_VERTS];
+    __shared__ CovTri s_tri[256];
+    __shared__ int s_count;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = blockIdx.y;
+    const int bx0 = (blockIdx.x % p.blocks_x) * COV_BLOCK, by0 = (blockIdx.x / p.blocks_x) * COV_BLOCK;
+    const int bx1 = min(bx0 + COV_BLOCK, p.width), by1 = min(by0 + COV_BLOCK, p.rows);
+
+    if (p.flags && p.flags[li]) {
+        // The light covers every pixel (coverage_classify_kernel): every tile of the block gets its pixels inside
+        // the image, which is what the rasterising path below arrives at triangle by triangle.
+        const int tx = (bx0 >> 3) + (tid & 15), ty = (by0 >> 3) + (tid >> 4);
+        if (tx < p.tiles_x && ty < p.tiles_y) {
+            const int cols = min(8, p.width - 8 * tx), rws = min(8, p.rows - 8 * ty);
+            const unsigned long long row_bits = (1ull << cols) - 1ull;  // cols <= 8
+            unsigned long long m = 0;
+            for (int r = 0; r < rws; r++) m |= row_bits << (8 * r);
+            p.masks[((size_t)li * p.tiles_y + ty) * p.tiles_x + tx] = m;
+        }
+        return;
+    }
+    transform_volume(p, li, s_vp, s_mvp, s_clip);
 
     const double sx = 2.0 / (double)p.width, sy = 2.0 / (double)p.frame_rows;
     // centres of the block's corner pixels
@@ -110,13 +187,8 @@ __global__ __launch_bounds__(256) void coverage_kernel(const CoverageParams p)
             }
             if (reject) goto next_triangle;
             {
-            const double x0 = c0.x, y0 = c0.y, w0 = c0.w, x1 = c1.x, y1 = c1.y, w1 = c1.w, x2 = c2.x, y2 = c2.y, w2 = c2.w;
             CovTri tr;
-            tr.a[0] = y1 * w2 - w1 * y2; tr.b[0] = w1 * x2 - x1 * w2; tr.c[0] = x1 * y2 - y1 * x2;
-            tr.a[1] = y2 * w0 - w2 * y0; tr.b[1] = w2 * x0 - x2 * w0; tr.c[1] = x2 * y0 - y2 * x0;
-            tr.a[2] = y0 * w1 - w0 * y1; tr.b[2] = w0 * x1 - x0 * w1; tr.c[2] = x0 * y1 - y0 * x1;
-            tr.z[0] = c0.z; tr.z[1] = c1.z; tr.z[2] = c2.z;
-            tr.D = __builtin_fma(w0, tr.c[0], __builtin_fma(y0, tr.b[0], x0 * tr.a[0]));
+            cov_setup(c0, c1, c2, tr);
             bool keep = tr.D > 0.0;  // back face; front faces and degenerate triangles are culled
 #pragma unroll
             for (int i = 0; i < 3; i++)  // an edge with all four corners outside rules the block out
@@ -214,13 +286,18 @@ extern "C" int32_t vkr_light_coverage(const VkrCoverageArgs *a, void *stream)
     CoverageParams p;
     p.width = a->width; p.rows = a->rows; p.frame_rows = a->frame_rows; p.row0 = a->row0;
     for (int i = 0; i < 16; i++) { p.view[i] = a->scene.camera_view[i]; p.proj[i] = a->scene.camera_projection[i]; }
-    p.lights = (const float *)a->lights;
+    p.lights = (const float *)a->lights; p.n_lights = a->n_lights;
+    p.flags = a->light_flags;
     p.verts = a->verts; p.n_verts = a->n_verts;
     p.indices = a->indices; p.n_tris = a->n_tris;
     p.masks = (unsigned long long *)a->masks;
     p.tiles_x = (a->width + 7) / 8; p.tiles_y = (a->rows + 7) / 8;
     p.blocks_x = (a->width + COV_BLOCK - 1) / COV_BLOCK;
     const int blocks_y = (a->rows + COV_BLOCK - 1) / COV_BLOCK;
+    if (p.flags) {
+        VKR_HIP_CHECK(hipMemsetAsync(p.flags + a->n_lights, 0, sizeof(unsigned), as_stream(stream)));
+        hipLaunchKernelGGL(coverage_classify_kernel, dim3((unsigned)a->n_lights), dim3(256), 0, as_stream(stream), p);
+    }
     hipLaunchKernelGGL(coverage_kernel, dim3((unsigned)(p.blocks_x * blocks_y), (unsigned)a->n_lights), dim3(256), 0, as_stream(stream), p);
     return launch_status("vkr_light_coverage");
 }

@@ -11,6 +11,7 @@
 // three x, three y and three z coordinates (v, v - r, v + r), so their face coordinates are
 // computed once per coordinate pair instead of once per tap; when every tap of every lane of the
 // wave falls on one cube face (the common case) the face selection disappears altogether.
+#include <type_traits>
 #include "vkr_device.h"
 #include "vkr_fastmath.h"
 #include "vkr_host.h"
@@ -33,6 +34,7 @@ struct ShadeParams {
     const uint32_t *brdf_lut; int lut_res;
     uint2 *out_color, *out_threshold;
     const unsigned long long *coverage;  // per (light, 8x8 tile) masks, or null
+    const unsigned *coverage_flags;      // with masks: word n_lights = number of lights that do not cover every pixel; or null
     float cam[3];
     float dir_dir[3];
     float dir_color[3];
@@ -481,6 +483,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         typedef const __attribute__((address_space(4))) unsigned long long cmask;
         cmask *cover_c = (cmask *)p.coverage;
         const size_t tiles = (size_t)p.tiles_x * p.tiles_y, tile = (size_t)tile_y * p.tiles_x + tile_x;
+        // The light loop, with or without the per-light masks.  A kernel built for masks holds both forms: when the
+        // coverage pass found that every light covers every pixel (the reference's own light radii, with the camera
+        // inside every volume) its waves take the form without masks, which costs neither the mask loads nor the
+        // selects.  The branch is wave-uniform and the same for every wave of a launch, so only one form is ever
+        // in the instruction cache.
+        auto light_loop = [&](auto use_masks) {
+        constexpr bool MASKS = decltype(use_masks)::value;
         for (int li = 0; li < p.n_lights; li++) {
             const f3 lp = lp_next, lc = lc_next;
             {
@@ -490,7 +499,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             }
             bool covered = true;
             unsigned long long cover_mask = ~0ull;
-            if (MASKED) {
+            if (MASKS) {
                 cover_mask = cover_c[(size_t)li * tiles + tile];  // wave-uniform: a scalar load
                 if (cover_mask == 0) continue;
                 covered = (cover_mask >> lane) & 1ull;
@@ -523,7 +532,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             // G-buffer values and light colours), and adding it leaves both targets as they are: a wave that
             // faces away from the light is done.  Masks of single comparisons are combined as scalars.
             unsigned long long live = __builtin_amdgcn_ballot_w64(slow_domain) | __builtin_amdgcn_ballot_w64(NdotL > 0.0f);
-            if (MASKED) live &= cover_mask;
+            if (MASKS) live &= cover_mask;
             if (live == 0ull) continue;
             const int face0 = wave_common_face(Fv.x, Fv.y, Fv.z, disk);
             float count;
@@ -558,7 +567,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             const float o2 = ((fma_((1.0f - F.z) * albedo.z, INV_PI, (DG * F.z) * isd) * (lc.z * att)) * lit) * NdotL;
             const bool over = luminance(o0, o1, o2) > 1.0f;  // light.frag:78-82
             const bool bright = covered && over;
-            if (MASKED) {  // an uncovered pixel is not part of this draw: its targets keep their bits
+            if (MASKS) {  // an uncovered pixel is not part of this draw: its targets keep their bits
                 c0 = covered ? round_f16(c0 + o0) : c0; c1 = covered ? round_f16(c1 + o1) : c1; c2 = covered ? round_f16(c2 + o2) : c2;
             } else {
                 c0 = round_f16(c0 + o0); c1 = round_f16(c1 + o1); c2 = round_f16(c2 + o2);
@@ -568,6 +577,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                 t1 = round_f16(t1 + (bright ? o1 : 0.0f));
                 t2 = round_f16(t2 + (bright ? o2 : 0.0f));
             }
+        }
+        };
+        if (MASKED) {
+            typedef const __attribute__((address_space(4))) unsigned cflag;
+            const bool every_light_covers_all = p.coverage_flags != nullptr && ((cflag *)p.coverage_flags)[p.n_lights] == 0u;
+            if (every_light_covers_all) light_loop(std::false_type{});
+            else light_loop(std::true_type{});
+        } else {
+            light_loop(std::false_type{});
         }
     }
     p.out_color[px] = pack4(c0, c1, c2, 1.0f);
@@ -648,6 +666,7 @@ extern "C" int32_t vkr_shade(const VkrShadeArgs *a, void *stream)
     p.brdf_lut = (const uint32_t *)a->brdf_lut; p.lut_res = a->lut_res;
     p.out_color = (uint2 *)a->out_color; p.out_threshold = (uint2 *)a->out_threshold;
     p.coverage = a->coverage_mode == VKR_COVERAGE_MESH ? (const unsigned long long *)a->coverage_masks : nullptr;
+    p.coverage_flags = p.coverage ? a->coverage_flags : nullptr;
     for (int i = 0; i < 3; i++) {
         p.cam[i] = a->scene.camera_position[i];
         p.dir_dir[i] = a->scene.dir_light_direction[i];

@@ -64,6 +64,7 @@ class DeviceFrame:
     background: torch.Tensor | None = None
     cube_layout: int = _lib.CUBE_LAYOUT_LINEAR
     coverage: torch.Tensor | None = None  # masks from light_coverage(); None: every light covers every pixel
+    coverage_flags: torch.Tensor | None = None  # per-light "covers every pixel" words of the same light_coverage() call
 
     @staticmethod
     def upload(f: FrameInputs, device, tiled: bool | None = None) -> "DeviceFrame":
@@ -89,10 +90,11 @@ class DeviceFrame:
 
 
 def light_coverage(f: DeviceFrame, verts: torch.Tensor, indices: torch.Tensor,
-                   frame_rows: int | None = None, row0: int = 0) -> torch.Tensor:
+                   frame_rows: int | None = None, row0: int = 0, flags: torch.Tensor | None = None) -> torch.Tensor:
     """Light-volume coverage of the frame's lights: int64 tensor [n_lights, ceil(rows/8), ceil(width/8)] of
     64-bit tile masks (bit (y&7)*8 + (x&7)).  `verts` [n,3] float32, `indices` [m,3] int32 on the device;
-    `frame_rows` / `row0` place a strip inside the whole frame."""
+    `frame_rows` / `row0` place a strip inside the whole frame.  `flags`: int32 tensor of n_lights + 1 words that
+    receives the per-light "covers every pixel" decisions (see light_coverage_with_flags)."""
     lib = _lib.load()
     masks = torch.empty((f.n_lights, (f.rows + 7) // 8, (f.width + 7) // 8), dtype=torch.int64, device=f.albedo.device)
     a = _lib.CoverageArgs()
@@ -102,8 +104,18 @@ def light_coverage(f: DeviceFrame, verts: torch.Tensor, indices: torch.Tensor,
     a.verts, a.n_verts = _ptr(verts), verts.shape[0]
     a.indices, a.n_tris = _ptr(indices), indices.shape[0]
     a.masks = _ptr(masks)
+    a.light_flags = _ptr(flags)
     _lib.check(lib.vkr_light_coverage(C.byref(a), _stream()))
     return masks
+
+
+def light_coverage_with_flags(f: DeviceFrame, verts: torch.Tensor, indices: torch.Tensor,
+                              frame_rows: int | None = None, row0: int = 0) -> tuple[torch.Tensor, torch.Tensor]:
+    """light_coverage() plus the per-light words: flags[i] = 1 when light i provably covers every pixel (its masks
+    are then all ones, written without rasterising), flags[n_lights] = the number of lights with a 0.  A frame that
+    carries both (DeviceFrame.coverage, .coverage_flags) is shaded without reading the masks when that number is 0."""
+    flags = torch.empty((f.n_lights + 1,), dtype=torch.int32, device=f.albedo.device)
+    return light_coverage(f, verts, indices, frame_rows, row0, flags), flags
 
 
 def _mesh_draws(draws):
@@ -217,6 +229,7 @@ def shade(f: DeviceFrame, out_color: torch.Tensor, out_threshold: torch.Tensor) 
     a.lights, a.n_lights = _ptr(f.lights), f.n_lights
     a.coverage_mode = _lib.COVERAGE_FULLSCREEN if f.coverage is None else _lib.COVERAGE_MESH
     a.coverage_masks = _ptr(f.coverage)
+    a.coverage_flags = _ptr(f.coverage_flags) if f.coverage is not None else None
     a.dir_shadow, a.dir_res = _ptr(f.dir_shadow), f.dir_shadow.shape[-1]
     a.cube_shadow, a.cube_res, a.cube_layout = _ptr(f.cube_shadow), f.cube_shadow.shape[-1], f.cube_layout
     a.irradiance, a.irr_res = _ptr(f.irradiance), f.irradiance.shape[1]

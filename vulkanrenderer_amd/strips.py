@@ -96,7 +96,8 @@ class HipBackend:
         """The strip's frame with light-volume masks attached; `volume_mesh` = (verts, triangles) device tensors."""
         import dataclasses
         verts, tris = volume_mesh
-        return dataclasses.replace(frame, coverage=self.P.light_coverage(frame, verts, tris, frame_rows, row0))
+        masks, flags = self.P.light_coverage_with_flags(frame, verts, tris, frame_rows, row0)
+        return dataclasses.replace(frame, coverage=masks, coverage_flags=flags)
 
     def bloom_post(self, thr, hdr, out, lo, hi, row0=0):
         # `thr` is the halo-padded thresholded image; output row k of `hdr`/`out` is strip row row0 + k, centred
