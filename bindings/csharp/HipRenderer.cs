@@ -15,7 +15,8 @@ namespace Renderer;
 public struct VkrConfig
 {
     public int Device, Width, Height, MaxLights, DirShadowRes, PointShadowRes, EnvRes,
-               IrradianceRes, PrefilterRes, PrefilterMips, BrdfLutRes, FramesInFlight, Flags;
+               IrradianceRes, PrefilterRes, PrefilterMips, BrdfLutRes, FramesInFlight, Flags,
+               FrameRows, Row0;   // rows [Row0, Row0 + Height) of a frame of FrameRows rows; 0, 0 = the whole frame
 }
 
 [StructLayout(LayoutKind.Sequential)]
@@ -48,6 +49,49 @@ internal static unsafe class Native
     [DllImport(Lib)] public static extern int vkr_read(nint ctx, int frame, int target, int mip, void* host, long hostBytes);
     [DllImport(Lib)] public static extern int vkr_sync(nint ctx);
     [DllImport(Lib)] public static extern int vkr_get_timing(nint ctx, out VkrTiming timing);
+    [DllImport(Lib)] public static extern int vkr_current_frame(nint ctx);
+    [DllImport(Lib)] public static extern int vkr_upload_env_cube(nint ctx, void* rgba16fCube);
+    // single passes, run at once
+    [DllImport(Lib)] public static extern int vkr_pass_composition(nint ctx);
+    [DllImport(Lib)] public static extern int vkr_pass_bloom(nint ctx, int horizontal);
+    [DllImport(Lib)] public static extern int vkr_pass_postprocess(nint ctx);
+    // RenderStage.cs:99-190
+    [DllImport(Lib)] public static extern int vkr_stage_reset_commands(nint ctx, int stage, int frame);
+    [DllImport(Lib)] public static extern int vkr_stage_begin_commands(nint ctx, int stage, int frame);
+    [DllImport(Lib)] public static extern int vkr_stage_begin_render_pass(nint ctx, int stage, int frame);
+    [DllImport(Lib)] public static extern int vkr_stage_draw(nint ctx, int stage, int frame);
+    [DllImport(Lib)] public static extern int vkr_stage_end_render_pass(nint ctx, int stage, int frame);
+    [DllImport(Lib)] public static extern int vkr_stage_end_commands(nint ctx, int stage, int frame);
+    [DllImport(Lib)] public static extern int vkr_submit_frame(nint ctx);
+    // strips: one frame on several GPUs
+    [DllImport(Lib)] public static extern int vkr_strip_plan(int frameRows, int nStrips, int k, out int row0, out int rows);
+    [DllImport(Lib)] public static extern int vkr_strip_shade(nint ctx);
+    [DllImport(Lib)] public static extern int vkr_strip_halo(nint ctx, int side, out nint send, out nint recv, out long bytes);
+    [DllImport(Lib)] public static extern int vkr_strip_exchange(nint upper, nint lower);
+    [DllImport(Lib)] public static extern int vkr_strip_finish(nint ctx);
+    [DllImport(Lib)] public static extern int vkr_resize_strip(nint ctx, int width, int height, int frameRows, int row0);
+}
+
+// VKR_STAGE_*: the reference's stage objects (VulkanRenderer.cs:80-88) in its submission order (:563-584)
+public enum HipStage { PointShadow = 0, Geometry = 1, DirectionalShadow = 2, Composition = 3, Bloom1 = 4, Bloom2 = 5, PostProcess = 6 }
+
+// RenderStage.cs with the same five calls and arguments, so that EndFrame can stay written as it is
+// (VulkanRenderer.cs:346-557): BeginCommands(currentFrame); BeginRenderPass(currentFrame, currentFrame); the stage's
+// vkCmdBind* / vkCmdDraw* calls become one Draw(currentFrame); EndRenderPass(currentFrame); EndCommands(currentFrame).
+// Nothing runs until HipRenderer.SubmitFrame(), which takes the place of vk.QueueSubmit + QueuePresent (:559-622).
+public sealed class HipRenderStage
+{
+    readonly nint ctx;
+    readonly int stage;
+    internal HipRenderStage(nint ctx, HipStage stage) { this.ctx = ctx; this.stage = (int) stage; }
+
+    public void ResetCommandBuffer(uint commandBufferIndex) => HipRenderer.Check(Native.vkr_stage_reset_commands(ctx, stage, (int) commandBufferIndex));
+    public void BeginCommands(uint commandBufferIndex) => HipRenderer.Check(Native.vkr_stage_begin_commands(ctx, stage, (int) commandBufferIndex));
+    // framebufferIndex selects nothing: the context owns one set of attachments per frame in flight
+    public void BeginRenderPass(uint commandBufferIndex, uint framebufferIndex) => HipRenderer.Check(Native.vkr_stage_begin_render_pass(ctx, stage, (int) commandBufferIndex));
+    public void Draw(uint commandBufferIndex) => HipRenderer.Check(Native.vkr_stage_draw(ctx, stage, (int) commandBufferIndex));
+    public void EndRenderPass(uint commandBufferIndex) => HipRenderer.Check(Native.vkr_stage_end_render_pass(ctx, stage, (int) commandBufferIndex));
+    public void EndCommands(uint commandBufferIndex) => HipRenderer.Check(Native.vkr_stage_end_commands(ctx, stage, (int) commandBufferIndex));
 }
 
 public sealed unsafe class HipRenderer : IDisposable
@@ -59,7 +103,7 @@ public sealed unsafe class HipRenderer : IDisposable
 
     public HipRenderer(in VkrConfig config) => Check(Native.vkr_create(config, out ctx));
 
-    static void Check(int rc)
+    internal static void Check(int rc)
     {
         // the reference throws Exception on any non-Success VkResult (e.g. VulkanRenderer.cs:589-594)
         if (rc < 0) throw new Exception(Marshal.PtrToStringUTF8((nint)Native.vkr_last_error()));
@@ -68,13 +112,62 @@ public sealed unsafe class HipRenderer : IDisposable
     public void UpdateSceneInfo(SceneInfo sceneInfo) => Check(Native.vkr_update_scene_info(ctx, sceneInfo));
     public void BeginFrame() => Check(Native.vkr_begin_frame(ctx));
 
-    public void EndFrame()
+    public void PushLights()
     {
         var infos = stackalloc LightInfo[Lights.Count];
         for (int i = 0; i < Lights.Count; i++) infos[i] = Lights[i].ToInfo();   // Light.cs:10
         Check(Native.vkr_set_lights(ctx, infos, Lights.Count, hasVolumeMesh ? 1 : 0));   // 1 = VKR_COVERAGE_MESH
+    }
+
+    // the whole frame in one call: both bloom passes and the post-process draw run as one kernel
+    public void EndFrame()
+    {
+        PushLights();
         Check(Native.vkr_end_frame(ctx));
     }
+
+    // EndFrame written stage by stage, as in the reference (VulkanRenderer.cs:320-623); the stage fields take the
+    // place of geometryRenderStage, compositionRenderStage, ... (:80-88)
+    public uint CurrentFrame => (uint) Native.vkr_current_frame(ctx);
+    public HipRenderStage Stage(HipStage stage) => new(ctx, stage);
+    public void SubmitFrame() => Check(Native.vkr_submit_frame(ctx));
+    public void EndFrameByStages(bool hasDrawCalls)
+    {
+        uint currentFrame = CurrentFrame;
+        PushLights();
+        foreach (HipStage id in Enum.GetValues<HipStage>())
+        {
+            // without draw calls the shadow maps and the G-buffer are the uploaded ones: those stages record nothing
+            if (!hasDrawCalls && id <= HipStage.DirectionalShadow) continue;
+            var stage = Stage(id);
+            stage.BeginCommands(currentFrame);
+            stage.BeginRenderPass(currentFrame, currentFrame);
+            stage.Draw(currentFrame);
+            stage.EndRenderPass(currentFrame);
+            stage.EndCommands(currentFrame);
+        }
+        SubmitFrame();
+    }
+
+    // One frame on several GPUs from this one process: a HipRenderer per GPU, each created with its strip
+    // (VkrConfig.Device / Height / FrameRows / Row0 from StripPlan); per frame every renderer gets the same
+    // BeginFrame / UpdateSceneInfo / Lights / DrawModel calls, then
+    //     foreach r: r.StripShade();   foreach neighbouring pair: HipRenderer.ExchangeHalo(upper, lower);   foreach r: r.StripFinish();
+    // and Read(frame, VKR_TARGET_LDR) of renderer k fills rows [Row0, Row0 + Height) of the image.
+    public static (int row0, int rows) StripPlan(int frameRows, int nStrips, int k)
+    {
+        Check(Native.vkr_strip_plan(frameRows, nStrips, k, out int row0, out int rows));
+        return (row0, rows);
+    }
+    public void StripShade() { PushLights(); Check(Native.vkr_strip_shade(ctx)); }
+    public void StripFinish() => Check(Native.vkr_strip_finish(ctx));
+    public static void ExchangeHalo(HipRenderer upper, HipRenderer lower) => Check(Native.vkr_strip_exchange(upper.ctx, lower.ctx));
+
+    // single passes, run at once on the context's stream (for tools that want one pass of a frame)
+    public void CompositionPass() { PushLights(); Check(Native.vkr_pass_composition(ctx)); }
+    public void BloomPass(bool horizontal) => Check(Native.vkr_pass_bloom(ctx, horizontal ? 1 : 0));
+    public void PostProcessPass() => Check(Native.vkr_pass_postprocess(ctx));
+    public void UploadEnvironmentCubemap(void* rgba16fCube) => Check(Native.vkr_upload_env_cube(ctx, rgba16fCube));
 
     // Mesh.cs keeps positions and indices on the device; DrawModel is VulkanRenderer.cs:630-633
     public int CreateMesh(float* positions, int nVerts, uint* indices, int nTris)

@@ -65,7 +65,7 @@ typedef struct VkrLightInfo {
 } VkrLightInfo;
 
 /* Which pixels a point light's draw touches (the reference rasterises a sphere mesh per light,
- * GraphicsPipeline.cs:100-117). */
+ * GraphicsPipeline.cs:100-117).  Both modes are implemented. */
 #define VKR_COVERAGE_FULLSCREEN 0 /* every light volume covers every pixel (exact while the camera is inside every volume) */
 #define VKR_COVERAGE_MESH 1       /* per-pixel coverage of the light-volume mesh, from vkr_light_coverage() */
 
@@ -333,6 +333,8 @@ typedef struct VkrConfig {
     int32_t brdf_lut_res;      /* (512) */
     int32_t frames_in_flight;  /* MaxFramesInFlight     (2) */
     int32_t flags;             /* VKR_POST_* */
+    int32_t frame_rows, row0;  /* the context renders rows [row0, row0 + height) of a frame of frame_rows rows
+                                  (see "Strips" below); 0, 0: the whole frame */
 } VkrConfig;
 
 #define VKR_TARGET_COLOR 0      /* composition colour, RGBA16F WxH */
@@ -394,10 +396,63 @@ VKR_EXPORT int32_t vkr_create_irradiance_cubemap(vkr_ctx *ctx, int32_t order);  
 VKR_EXPORT int32_t vkr_create_prefiltered_cubemap(vkr_ctx *ctx);                 /* :815 */
 VKR_EXPORT int32_t vkr_create_brdf_lut(vkr_ctx *ctx);                            /* :966 */
 
-/* Individual passes of EndFrame, for callers that mirror RenderStage's begin/draw/end shape. */
+/* Individual passes of EndFrame, run at once on the context's stream.  vkr_pass_composition includes the shadow,
+ * geometry, coverage and skybox work of the frame's draw calls; the bloom passes store VKR_TARGET_BLOOM1 / _BLOOM2. */
 VKR_EXPORT int32_t vkr_pass_composition(vkr_ctx *ctx);
 VKR_EXPORT int32_t vkr_pass_bloom(vkr_ctx *ctx, int32_t horizontal);
 VKR_EXPORT int32_t vkr_pass_postprocess(vkr_ctx *ctx);
+
+/* RenderStage (RenderStage.cs:99-190) for a caller that keeps the reference's recording shape: per stage
+ * BeginCommands -> BeginRenderPass -> the stage's draws -> EndRenderPass -> EndCommands, as VulkanRenderer.EndFrame
+ * does for each of its stages (VulkanRenderer.cs:346-374, 380-403, 408-427, 432-500, 504-521, 523-540, 544-557), then
+ * one submission (VulkanRenderer.cs:559-595).  `stage` names the reference's stage object; `frame` is its
+ * commandBufferIndex and must be vkr_current_frame().  Recording runs nothing: vkr_submit_frame runs the recorded
+ * stages in the reference's submission order (the numbering below), then advances the frame index like EndFrame.
+ * vkr_stage_draw records all draws the reference records into that stage (per light for the point-shadow stage and
+ * the light volumes; per draw call for the geometry and shadow stages).  A render pass without draws leaves its
+ * attachments at the reference's clear values; a stage that recorded nothing leaves its images as they are (uploaded,
+ * or from an earlier frame).  Every bloom image is stored, as in the reference (vkr_end_frame stores none).
+ * Calls out of order fail with VKR_ERR_ORDER, as the reference throws on a failed vkBegin/EndCommandBuffer
+ * (RenderStage.cs:106-121).  vkr_begin_frame resets every stage (VulkanRenderer.cs:307-314). */
+#define VKR_STAGE_POINT_SHADOW 0  /* pointShadowRenderStages[0 .. Lights.Count) */
+#define VKR_STAGE_GEOMETRY 1      /* geometryRenderStage */
+#define VKR_STAGE_DIR_SHADOW 2    /* depthMapRenderStage */
+#define VKR_STAGE_COMPOSITION 3   /* compositionRenderStage: skybox, composition and light-volume draws */
+#define VKR_STAGE_BLOOM1 4        /* bloomRenderStage1 */
+#define VKR_STAGE_BLOOM2 5        /* bloomRenderStage2 */
+#define VKR_STAGE_POSTPROCESS 6   /* postProcessRenderStage */
+#define VKR_STAGE_COUNT 7
+VKR_EXPORT int32_t vkr_stage_reset_commands(vkr_ctx *ctx, int32_t stage, int32_t frame);     /* ResetCommandBuffer, :187 */
+VKR_EXPORT int32_t vkr_stage_begin_commands(vkr_ctx *ctx, int32_t stage, int32_t frame);     /* BeginCommands, :99 */
+VKR_EXPORT int32_t vkr_stage_begin_render_pass(vkr_ctx *ctx, int32_t stage, int32_t frame);  /* BeginRenderPass, :132 */
+VKR_EXPORT int32_t vkr_stage_draw(vkr_ctx *ctx, int32_t stage, int32_t frame);               /* the vkCmdDraw* calls EndFrame records */
+VKR_EXPORT int32_t vkr_stage_end_render_pass(vkr_ctx *ctx, int32_t stage, int32_t frame);    /* EndRenderPass, :177 */
+VKR_EXPORT int32_t vkr_stage_end_commands(vkr_ctx *ctx, int32_t stage, int32_t frame);       /* EndCommands, :116 */
+VKR_EXPORT int32_t vkr_submit_frame(vkr_ctx *ctx);                                           /* QueueSubmit + present + advance, VulkanRenderer.cs:559-622 */
+
+/* Strips: one frame on several GPUs.  The reference renders on one device; its passes shard by rows, so a host gives
+ * each GPU a context for rows [row0, row0 + height) of the frame (VkrConfig.frame_rows / row0; vkr_strip_plan cuts a
+ * frame into n near-equal strips), feeds every context the same scene, lights, draw calls and IBL source and its own
+ * rows of any uploaded image, and ends a frame in three steps instead of vkr_end_frame:
+ *   vkr_strip_shade(ctx)      every pass up to the composition pass, for the strip (asynchronous);
+ *   the halo rows             bloom pass 2 reads VKR_STRIP_HALO_ROWS rows of the thresholded image beyond each strip
+ *                             edge that is not a frame edge.  Contexts of one process: vkr_strip_exchange(upper, lower)
+ *                             per neighbouring pair (device-to-device copies, over xGMI between GPUs, ordered on the
+ *                             contexts' streams: the host waits for nothing).  Contexts of different processes:
+ *                             vkr_strip_halo gives the device pointers to send from and receive into (RCCL / MPI /
+ *                             IPC of the host's choice, after vkr_sync and before vkr_strip_finish);
+ *   vkr_strip_finish(ctx)     bloom 1, bloom 2 and post-process for the strip; advances the frame index.
+ * vkr_read returns the strip's rows; the strips stacked in row order are the frame, bit for bit the image one
+ * context renders alone (no pass reduces across rows).  Shadow maps and IBL images are rendered per context. */
+#define VKR_STRIP_HALO_ROWS 4 /* bloom_blur.frag:20-23 reaches 4 texels to each side */
+#define VKR_STRIP_ABOVE 0
+#define VKR_STRIP_BELOW 1
+VKR_EXPORT int32_t vkr_strip_plan(int32_t frame_rows, int32_t n_strips, int32_t k, int32_t *row0, int32_t *rows);
+VKR_EXPORT int32_t vkr_strip_shade(vkr_ctx *ctx);
+VKR_EXPORT int32_t vkr_strip_halo(vkr_ctx *ctx, int32_t side, const void **send, void **recv, int64_t *bytes);
+VKR_EXPORT int32_t vkr_strip_exchange(vkr_ctx *upper, vkr_ctx *lower);
+VKR_EXPORT int32_t vkr_strip_finish(vkr_ctx *ctx);
+VKR_EXPORT int32_t vkr_resize_strip(vkr_ctx *ctx, int32_t width, int32_t height, int32_t frame_rows, int32_t row0);
 
 /* Copies a target of frame `frame` (or an IBL image) to host memory; waits for pending work. */
 VKR_EXPORT int32_t vkr_read(vkr_ctx *ctx, int32_t frame, int32_t target, int32_t mip, void *host, int64_t host_bytes);

@@ -11,6 +11,8 @@
 //   BeginFrame() / EndFrame()    VulkanRenderer.cs:286 / :320
 //   CreateSkyboxCubemap() ...    VulkanRenderer.cs:653, :734, :815, :966
 //   WaitIdle(), Dispose (RAII)   as in the reference's IDisposable wrappers
+//   HipRenderStage               RenderStage.cs:99-190 (BeginCommands / BeginRenderPass / EndRenderPass / EndCommands),
+//                                for a host that keeps EndFrame's per-stage recording; SubmitFrame() is its QueueSubmit
 #pragma once
 #include <cmath>
 #include <cstdint>
@@ -57,6 +59,33 @@ struct Light {
     }
 };
 
+class HipRenderer;
+
+// RenderStage.cs: one object per pass of the frame.  The five calls have the reference's names and arguments
+// (commandBufferIndex = the current frame); Draw() stands for the vkCmdBind* / vkCmdDraw* calls EndFrame records
+// between BeginRenderPass and EndRenderPass of that stage.  Nothing runs until HipRenderer::SubmitFrame().
+class HipRenderStage {
+public:
+    void ResetCommandBuffer(uint32_t commandBufferIndex) { check(vkr_stage_reset_commands(ctx_, stage_, (int32_t)commandBufferIndex)); }
+    void BeginCommands(uint32_t commandBufferIndex) { check(vkr_stage_begin_commands(ctx_, stage_, (int32_t)commandBufferIndex)); }
+    // framebufferIndex is the frame in flight again (the swapchain image for the post-process stage): the
+    // renderer object owns one set of attachments per frame in flight, so it selects nothing here
+    void BeginRenderPass(uint32_t commandBufferIndex, uint32_t framebufferIndex)
+    {
+        (void)framebufferIndex;
+        check(vkr_stage_begin_render_pass(ctx_, stage_, (int32_t)commandBufferIndex));
+    }
+    void Draw(uint32_t commandBufferIndex) { check(vkr_stage_draw(ctx_, stage_, (int32_t)commandBufferIndex)); }
+    void EndRenderPass(uint32_t commandBufferIndex) { check(vkr_stage_end_render_pass(ctx_, stage_, (int32_t)commandBufferIndex)); }
+    void EndCommands(uint32_t commandBufferIndex) { check(vkr_stage_end_commands(ctx_, stage_, (int32_t)commandBufferIndex)); }
+
+private:
+    friend class HipRenderer;
+    HipRenderStage(vkr_ctx *ctx, int32_t stage) : ctx_(ctx), stage_(stage) {}
+    vkr_ctx *ctx_;
+    int32_t stage_;
+};
+
 class HipRenderer {
 public:
     std::vector<Light> Lights;  // VulkanRenderer.cs:65
@@ -75,12 +104,28 @@ public:
     void BeginFrame() { check(vkr_begin_frame(ctx_)); }
     void EndFrame()
     {
+        PushLights();
+        check(vkr_end_frame(ctx_));
+    }
+    // The stage objects of the reference (VulkanRenderer.cs:80-88): Stage(VKR_STAGE_GEOMETRY) is geometryRenderStage, ...
+    HipRenderStage Stage(int32_t stage) { return HipRenderStage(ctx_, stage); }
+    // What EndFrame does before and after its stages: the light records go up (they are push constants of the light
+    // draws in the reference, VulkanRenderer.cs:485-497), ...
+    void PushLights()
+    {
         std::vector<VkrLightInfo> infos;
         infos.reserve(Lights.size());
         for (const Light &l : Lights) infos.push_back(l.ToInfo());
         check(vkr_set_lights(ctx_, infos.data(), (int32_t)infos.size(), has_volume_mesh_ ? VKR_COVERAGE_MESH : VKR_COVERAGE_FULLSCREEN));
-        check(vkr_end_frame(ctx_));
     }
+    // ... and the recorded stages are submitted (VulkanRenderer.cs:559-622): they run in the reference's submission
+    // order, then the frame index advances.
+    void SubmitFrame() { check(vkr_submit_frame(ctx_)); }
+    // One frame on several GPUs: every renderer owns a strip of the frame (VkrConfig.frame_rows / row0) and ends a
+    // frame with StripShade(), ExchangeHalo() per neighbouring pair, StripFinish().
+    void StripShade() { PushLights(); check(vkr_strip_shade(ctx_)); }
+    void StripFinish() { check(vkr_strip_finish(ctx_)); }
+    static void ExchangeHalo(HipRenderer &upper, HipRenderer &lower) { check(vkr_strip_exchange(upper.ctx_, lower.ctx_)); }
     // Mesh.cs / VulkanRenderer.DrawModel (VulkanRenderer.cs:630-633): with draw calls in a frame, EndFrame renders
     // the shadow maps from them.
     int32_t CreateMesh(const float *positions, int32_t n_verts, const uint32_t *indices, int32_t n_tris)

@@ -9,6 +9,9 @@
 //   optional trailer: int32 n_draws; per draw: int32 n_verts, n_tris; positions (3 f32 per vertex), texcoords (2),
 //   normals (3), tangents (3); indices (3 u32 per triangle); model (16 f32); three RGBA8 images, each int32 w, h + bytes.
 //   With draws the frame is rendered from them (CreateMesh / CreateMaterial / DrawModel): nothing is uploaded.
+// A third argument "stages" ends each frame the way VulkanRenderer.EndFrame is written (VulkanRenderer.cs:346-557):
+// every pass recorded into its RenderStage by BeginCommands / BeginRenderPass / draws / EndRenderPass / EndCommands,
+// then one submission; the shadow and geometry stages are recorded only when the frame has draw calls.
 // output file: colour, threshold (w*h*8 B each), ldr (w*h*4 B), irradiance cube, prefilter mip 0, LUT
 #include <cstdio>
 #include <cstdlib>
@@ -22,7 +25,8 @@ static void read_exact(FILE *f, void *dst, size_t n)
 
 int main(int argc, char **argv)
 {
-    if (argc != 3) { fprintf(stderr, "usage: %s <in> <out>\n", argv[0]); return 2; }
+    if (argc != 3 && argc != 4) { fprintf(stderr, "usage: %s <in> <out> [stages]\n", argv[0]); return 2; }
+    const bool by_stages = argc == 4 && std::string(argv[3]) == "stages";
     FILE *in = fopen(argv[1], "rb");
     if (!in) { perror(argv[1]); return 2; }
     int32_t h9[9];
@@ -99,7 +103,24 @@ int main(int argc, char **argv)
                     r.DrawModel(meshes[i], m, materials[i]);
                 }
             }
-            r.EndFrame();
+            if (!by_stages) { r.EndFrame(); continue; }
+            const uint32_t currentFrame = (uint32_t)frame;
+            r.PushLights();
+            for (int32_t id = 0; id < VKR_STAGE_COUNT; id++) {
+                const bool from_draws = id == VKR_STAGE_POINT_SHADOW || id == VKR_STAGE_GEOMETRY || id == VKR_STAGE_DIR_SHADOW;
+                if (from_draws && draws.empty()) continue;  // uploaded images take these stages' place
+                vkr::HipRenderStage stage = r.Stage(id);
+                stage.BeginCommands(currentFrame);
+                stage.BeginRenderPass(currentFrame, currentFrame);
+                stage.Draw(currentFrame);
+                stage.EndRenderPass(currentFrame);
+                stage.EndCommands(currentFrame);
+            }
+            // recording out of order fails the way a failed vkBeginCommandBuffer / vkEndCommandBuffer throws
+            bool threw = false;
+            try { r.Stage(VKR_STAGE_BLOOM1).BeginRenderPass(currentFrame, currentFrame); } catch (const vkr::Error &) { threw = true; }
+            if (!threw) { fprintf(stderr, "BeginRenderPass on an ended command buffer did not throw\n"); return 3; }
+            r.SubmitFrame();
         }
         r.WaitIdle();
         bool threw = false;  // EndFrame without BeginFrame throws, as VulkanRenderer.cs:322

@@ -280,6 +280,90 @@ def test_renderer_end_frame_matches_oracle_chain(gpu, oracle):
             r.BeginFrame()
 
 
+def test_render_stages_record_and_submit_like_the_reference(gpu, oracle):
+    """Layer 2 through the RenderStage mirror: the five calls per stage, one submission; every attachment of the
+    frame (both bloom images included) equals the oracle's chain; order errors; a render pass without draws leaves
+    its attachments at the clear values; a stage that records nothing leaves its images alone."""
+    from vulkanrenderer_amd.renderer import HipRenderer
+    w, h, nl = 120, 72, 4
+    f = synth.make_frame(31, w, h, nl, 32, 128, irr_res=8, pref_res=16, lut_res=32)
+    with HipRenderer(w, h, max_lights=8, dir_shadow_res=128, point_shadow_res=32, env_res=16,
+                     irradiance_res=8, prefilter_res=16, prefilter_mips=2, brdf_lut_res=32) as r:
+        env = synth.make_env_cube(np.random.default_rng(2), 16)
+        r.UploadEnvironmentCubemap(env)
+        r.CreateIrradianceCubemap(); r.CreatePrefilteredCubemap(); r.CreateBRDFLUTTexture()
+        f.irradiance = r.Read(_lib.TARGET_IRRADIANCE)
+        f.prefilter = r.Read(_lib.TARGET_PREFILTER, mip=0)
+        f.brdf_lut = r.Read(_lib.TARGET_BRDF_LUT)
+        want = oracle.frame_chain(f, oracle.skybox(env, f.scene, w, h))
+        screen_stages = (_lib.STAGE_COMPOSITION, _lib.STAGE_BLOOM1, _lib.STAGE_BLOOM2, _lib.STAGE_POSTPROCESS)
+
+        def upload():
+            r.UpdateSceneInfo(f.scene)
+            r.UploadGBuffer(f.albedo, f.normal, f.arm, f.position)
+            r.UploadDirectionalShadowMap(f.dir_shadow)
+            for i in range(nl):
+                r.UploadPointShadowMap(i, f.cube_shadow[i])
+            r.SetLightInfos(f.lights)
+
+        def record(stage, cf, draw=True):
+            st = r.Stage(stage)
+            st.BeginCommands(cf)
+            st.BeginRenderPass(cf, cf)
+            if draw:
+                st.Draw(cf)
+            st.EndRenderPass(cf)
+            st.EndCommands(cf)
+
+        for _ in range(3):  # both frames in flight
+            cf = r.CurrentFrame
+            r.BeginFrame()
+            upload()
+            for stage in screen_stages:  # the geometry and shadow stages record nothing: their images are the uploads
+                record(stage, cf)
+            r.SubmitFrame()
+            assert r.CurrentFrame == (cf + 1) % 2
+            for target, name in ((_lib.TARGET_COLOR, "color"), (_lib.TARGET_THRESHOLD, "threshold"), (_lib.TARGET_BLOOM1, "bloom1"), (_lib.TARGET_BLOOM2, "bloom2")):
+                assert_bits_equal(r.Read(target, cf), want[name], name)
+            assert np.abs(r.Read(_lib.TARGET_LDR, cf).astype(np.int32) - want["ldr"].astype(np.int32)).max() <= 1
+
+        cf = r.CurrentFrame
+        with pytest.raises(_lib.VkrError):      # no frame begun
+            r.SubmitFrame()
+        r.BeginFrame()
+        upload()
+        st = r.Stage(_lib.STAGE_COMPOSITION)
+        with pytest.raises(_lib.VkrError):      # render pass before BeginCommands
+            st.BeginRenderPass(cf, cf)
+        with pytest.raises(_lib.VkrError):      # another frame's command buffer
+            st.BeginCommands(cf ^ 1)
+        st.BeginCommands(cf)
+        with pytest.raises(_lib.VkrError):      # already recording
+            st.BeginCommands(cf)
+        with pytest.raises(_lib.VkrError):      # draw outside a render pass
+            st.Draw(cf)
+        st.BeginRenderPass(cf, cf)
+        with pytest.raises(_lib.VkrError):      # EndCommands inside a render pass
+            st.EndCommands(cf)
+        with pytest.raises(_lib.VkrError):      # a stage still recording cannot be submitted
+            r.SubmitFrame()
+        st.Draw(cf)
+        st.EndRenderPass(cf)
+        st.EndCommands(cf)
+        record(_lib.STAGE_GEOMETRY, cf, draw=False)   # cleared G-buffer: the composition draw discards every pixel
+        record(_lib.STAGE_BLOOM1, cf, draw=False)     # bloom 1 at its clear value (0, 0, 0, 1)
+        record(_lib.STAGE_BLOOM2, cf)
+        record(_lib.STAGE_POSTPROCESS, cf)
+        r.SubmitFrame()
+        sky = oracle.skybox(env, f.scene, w, h)
+        assert_bits_equal(r.Read(_lib.TARGET_COLOR, cf)[..., :3], sky[..., :3], "skybox behind a cleared G-buffer")
+        b1 = r.Read(_lib.TARGET_BLOOM1, cf)
+        assert (b1[..., :3] == 0).all() and (b1[..., 3] == 0x3C00).all()
+        assert (r.Read(_lib.TARGET_BLOOM2, cf)[..., :3] == 0).all()
+        want_ldr = oracle.postprocess(np.ascontiguousarray(r.Read(_lib.TARGET_COLOR, cf)), np.ascontiguousarray(r.Read(_lib.TARGET_BLOOM2, cf)))
+        assert np.abs(r.Read(_lib.TARGET_LDR, cf).astype(np.int32) - want_ldr.astype(np.int32)).max() <= 1
+
+
 def test_strip_pair_with_local_halo_copy_matches_whole_frame(gpu, oracle):
     """Two strips of one frame rendered by two StripRenderers on one GPU, the halo rows copied
     between them where the ranks of a real run would send them: exercises the split launches
@@ -334,9 +418,12 @@ def test_ibl_precompute_matches_oracle_at_cube_edges_and_corners(gpu, oracle):
     assert_bits_equal(P.f16_bits(res["brdf_lut"]), oracle.brdf_lut(48), "BRDF LUT")
 
 
-def test_cpp_host_program_matches_oracle(gpu, oracle, tmp_path):
+@pytest.mark.parametrize("mode", ["end_frame", "stages"])
+def test_cpp_host_program_matches_oracle(gpu, oracle, tmp_path, mode):
     """tests/cpp/renderer_roundtrip (built by __graft_entry__.build()) drives vkr::HipRenderer from
-    C++ the way the reference's render loop drives VulkanRenderer; its frame equals the oracle's."""
+    C++ the way the reference's render loop drives VulkanRenderer; its frame equals the oracle's.
+    "stages": every pass recorded through vkr::HipRenderStage's five calls (RenderStage.cs:99-190), then one
+    submission, instead of EndFrame."""
     import os
     import subprocess
     exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "renderer_roundtrip")
@@ -353,7 +440,7 @@ def test_cpp_host_program_matches_oracle(gpu, oracle, tmp_path):
             fh.write(np.asarray(l["color"][:3], dtype=np.float32).tobytes())
         for a in (f.albedo, f.normal, f.arm, f.position, f.dir_shadow, f.cube_shadow, env):
             fh.write(np.ascontiguousarray(a).tobytes())
-    proc = subprocess.run([exe, str(inp), str(outp)], capture_output=True, text=True, timeout=100)
+    proc = subprocess.run([exe, str(inp), str(outp)] + (["stages"] if mode == "stages" else []), capture_output=True, text=True, timeout=100)
     assert proc.returncode == 0, proc.stderr
     raw = np.fromfile(outp, dtype=np.uint8)
     sizes = [w * h * 8, w * h * 8, w * h * 4, 6 * ires * ires * 8, 6 * pres * pres * 8, lres * lres * 4]
@@ -892,6 +979,98 @@ def test_renderer_renders_a_frame_from_draw_calls_only(gpu, oracle):
         assert bare.any() and not bare.all() and np.array_equal(color[bare], sky[bare])
 
 
+@pytest.mark.parametrize("n_strips", [2, 3])
+def test_strip_contexts_of_one_process_equal_one_context(gpu, oracle, n_strips):
+    """Layer 2 on several GPUs from one process, rehearsed with every context on this GPU: a frame from draw calls
+    (shadow passes, geometry pass, skybox, light volumes) rendered as strips by `n_strips` renderer objects whose
+    boundary rows move with vkr_strip_exchange, against the same frame rendered by one object; two frames per
+    slot so that a strip's lent rows are overwritten while frames are in flight.  Also the ragged plan, the
+    order errors and a strip whose halo rows travel through pointers from vkr_strip_halo."""
+    from vulkanrenderer_amd.renderer import HipRenderer, strip_exchange, strip_plan
+    torch = _torch()
+    w, h, nl = 144, 83, 3
+    draws = _gpass_scene(w, h)
+    f = synth.make_frame(78, w, h, nl, 32, 64, irr_res=8, pref_res=16, lut_res=32)
+    # one light set per frame: bright ones (bloom to spread across the cuts) and small volumes (masks) in turn
+    lights = [synth.make_lights(np.random.default_rng(6 + k), nl) if k % 2 == 0 else _small_lights(np.random.default_rng(6 + k), nl, 0.3) for k in range(4)]
+    bloom_seen = 0
+    sphere = synth.make_sphere_mesh()
+    env = synth.make_env_cube(np.random.default_rng(2), 16)
+    kw = dict(max_lights=4, dir_shadow_res=64, point_shadow_res=32, env_res=16, irradiance_res=8, prefilter_res=16, prefilter_mips=1, brdf_lut_res=32)
+    plans = [strip_plan(h, n_strips, k) for k in range(n_strips)]
+    assert plans[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(plans, plans[1:])) and plans[-1][0] + plans[-1][1] == h
+    with pytest.raises(_lib.VkrError):
+        strip_plan(10, 3, 0)  # strips of fewer than four rows
+    whole = HipRenderer(w, h, **kw)
+    strips = [HipRenderer(w, rows, frame_rows=h, row0=row0, **kw) for row0, rows in plans]
+    try:
+        for r in [whole] + strips:
+            r.UploadEnvironmentCubemap(env)
+            r.CreateIrradianceCubemap(); r.CreatePrefilteredCubemap(); r.CreateBRDFLUTTexture()
+            r.SetLightVolumeMesh(*sphere)
+            r.handles = []
+            for d in draws:
+                mesh = r.CreateMesh(d["positions"], d["triangles"], d["texcoords"], d["normals"], d["tangents"])
+                r.handles.append((mesh, r.CreateMaterial(d["albedo"], d["normal"], d["arm"]), d["model"]))
+
+        def begin(r, k):
+            scene = _camera_scene((2.0 + 0.1 * k, 1.6, -4.0), aspect=w / h)
+            if k % 2 == 0:
+                scene["dir_light_color"] = (40.0, 36.0, 30.0)  # a sun bright enough to pass the bloom threshold
+            r.UpdateSceneInfo(scene)
+            r.SetLightInfos(lights[k], _lib.COVERAGE_MESH)
+            r.BeginFrame()
+            for mesh, material, model in r.handles:
+                r.DrawModel(mesh, model, material)
+
+        for k in range(4):
+            slot = whole.CurrentFrame
+            begin(whole, k)
+            whole._call(whole._lib.vkr_end_frame)
+            for r in strips:
+                begin(r, k)
+            with pytest.raises(_lib.VkrError):      # a strip cannot end its frame alone
+                strips[0]._call(strips[0]._lib.vkr_end_frame)
+            with pytest.raises(_lib.VkrError):      # nothing shaded yet
+                strip_exchange(strips[0], strips[1])
+            for r in strips:
+                r._call(r._lib.vkr_strip_shade)
+            with pytest.raises(_lib.VkrError):      # not neighbours in this order
+                strip_exchange(strips[1], strips[0])
+            if k % 2 == 0:
+                for up, lo in zip(strips, strips[1:]):
+                    strip_exchange(up, lo)
+            else:  # the same rows through the pointers a host with its own transport would use
+                for up, lo in zip(strips, strips[1:]):
+                    up.WaitIdle(); lo.WaitIdle()
+                    us, ur, n = up.StripHalo(_lib.STRIP_BELOW)
+                    ls, lr, n2 = lo.StripHalo(_lib.STRIP_ABOVE)
+                    assert n == n2 == w * 4 * 8
+                    _lib.check(_hip_memcpy_d2d(lr, us, n)); _lib.check(_hip_memcpy_d2d(ur, ls, n))
+            with pytest.raises(_lib.VkrError):
+                strips[0].StripHalo(_lib.STRIP_ABOVE)   # the top strip has no neighbour above
+            for r in strips:
+                r.StripFinish()
+            for target in (_lib.TARGET_COLOR, _lib.TARGET_THRESHOLD, _lib.TARGET_LDR):
+                got = np.concatenate([r.Read(target, slot)[:rows] for r, (_, rows) in zip(strips, plans)], 0)
+                assert np.array_equal(got, whole.Read(target, slot)), f"frame {k}, target {target}: the stacked strips differ from the whole frame"
+            thr = whole.Read(_lib.TARGET_THRESHOLD, slot)[..., :3]
+            cuts = [row0 for row0, _ in plans[1:]]
+            bloom_seen += int(any((thr[c - 4:c + 4] != 0).any() for c in cuts))  # bright pixels within reach of a cut
+        assert bloom_seen >= 2
+    finally:
+        for r in [whole] + strips:
+            r.Dispose()
+
+
+def _hip_memcpy_d2d(dst, src, n):
+    """hipMemcpy device to device through the HIP runtime the library links (test plumbing for vkr_strip_halo)."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    return -abs(hip.hipMemcpy(dst, src, n, 3))  # 3 = hipMemcpyDeviceToDevice; 0 on success
+
+
 def test_large_triangles_are_shared_by_the_wave(gpu, oracle):
     """Triangles whose bounding boxes hold far more samples than one lane should walk (a floor of two
     triangles under the scene, seen by the camera and by the lights) give the oracle's bits too."""
@@ -922,9 +1101,12 @@ def test_large_triangles_are_shared_by_the_wave(gpu, oracle):
     assert np.array_equal(got_dir.cpu().numpy().view(np.uint32), want_dir.view(np.uint32))
 
 
-def test_cpp_host_program_renders_from_draw_calls(gpu, oracle, tmp_path):
+@pytest.mark.parametrize("mode", ["end_frame", "stages"])
+def test_cpp_host_program_renders_from_draw_calls(gpu, oracle, tmp_path, mode):
     """The C++ mirror driven like the reference's render loop with models only: CreateMesh, CreateMaterial,
-    DrawModel between BeginFrame and EndFrame; its frame equals the oracle's geometry + shadow + shading chain."""
+    DrawModel between BeginFrame and EndFrame; its frame equals the oracle's geometry + shadow + shading chain.
+    "stages": the seven passes recorded stage by stage (point shadows, geometry, directional shadow, composition,
+    bloom 1, bloom 2, post-process) and submitted once, as VulkanRenderer.EndFrame is written."""
     import os
     import subprocess
     exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "renderer_roundtrip")
@@ -953,7 +1135,7 @@ def test_cpp_host_program_renders_from_draw_calls(gpu, oracle, tmp_path):
             for k in ("albedo", "normal", "arm"):
                 fh.write(np.array([d[k].shape[1], d[k].shape[0]], dtype=np.int32).tobytes())
                 fh.write(np.ascontiguousarray(d[k], dtype=np.uint8).tobytes())
-    proc = subprocess.run([exe, str(inp), str(outp)], capture_output=True, text=True, timeout=100)
+    proc = subprocess.run([exe, str(inp), str(outp)] + (["stages"] if mode == "stages" else []), capture_output=True, text=True, timeout=100)
     assert proc.returncode == 0, proc.stderr
     raw = np.fromfile(outp, dtype=np.uint8)
     sizes = [w * h * 8, w * h * 8, w * h * 4, 6 * ires * ires * 8, 6 * pres * pres * 8, lres * lres * 4]

@@ -24,6 +24,9 @@ GBUFFER_STATIC_MAX_PIXELS, GBUFFER_STATIC_MAX_DRAWS = 2097152, 64
 IRRADIANCE_SEQUENTIAL, IRRADIANCE_PHI_SLICES = 0, 1
 (TARGET_COLOR, TARGET_THRESHOLD, TARGET_BLOOM1, TARGET_BLOOM2, TARGET_LDR,
  TARGET_ENV, TARGET_IRRADIANCE, TARGET_PREFILTER, TARGET_BRDF_LUT) = range(9)
+(STAGE_POINT_SHADOW, STAGE_GEOMETRY, STAGE_DIR_SHADOW, STAGE_COMPOSITION, STAGE_BLOOM1, STAGE_BLOOM2, STAGE_POSTPROCESS) = range(7)
+STAGE_COUNT = 7
+STRIP_HALO_ROWS, STRIP_ABOVE, STRIP_BELOW = 4, 0, 1
 
 
 class VkrError(RuntimeError):
@@ -126,7 +129,8 @@ class BloomChainArgs(C.Structure):
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "device", "width", "height", "max_lights", "dir_shadow_res", "point_shadow_res", "env_res",
-        "irradiance_res", "prefilter_res", "prefilter_mips", "brdf_lut_res", "frames_in_flight", "flags")]
+        "irradiance_res", "prefilter_res", "prefilter_mips", "brdf_lut_res", "frames_in_flight", "flags",
+        "frame_rows", "row0")]
 
 
 class Timing(C.Structure):
@@ -184,6 +188,19 @@ PROTOTYPES = {
     "vkr_create_brdf_lut": [_vp],
     "vkr_pass_composition": [_vp],
     "vkr_pass_bloom": [_vp, _i32],
+    "vkr_stage_reset_commands": [_vp, _i32, _i32],
+    "vkr_stage_begin_commands": [_vp, _i32, _i32],
+    "vkr_stage_begin_render_pass": [_vp, _i32, _i32],
+    "vkr_stage_draw": [_vp, _i32, _i32],
+    "vkr_stage_end_render_pass": [_vp, _i32, _i32],
+    "vkr_stage_end_commands": [_vp, _i32, _i32],
+    "vkr_submit_frame": [_vp],
+    "vkr_strip_plan": [_i32, _i32, _i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
+    "vkr_strip_shade": [_vp],
+    "vkr_strip_halo": [_vp, _i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)],
+    "vkr_strip_exchange": [_vp, _vp],
+    "vkr_strip_finish": [_vp],
+    "vkr_resize_strip": [_vp, _i32, _i32, _i32, _i32],
     "vkr_pass_postprocess": [_vp],
     "vkr_read": [_vp, _i32, _i32, _i32, _vp, C.c_int64],
     "vkr_sync": [_vp],

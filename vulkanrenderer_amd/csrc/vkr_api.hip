@@ -32,6 +32,7 @@ struct Frame {
     int coverage = VKR_COVERAGE_FULLSCREEN;
     VkrSceneInfo scene;
     void *color = nullptr, *threshold = nullptr, *bloom1 = nullptr, *bloom2 = nullptr, *ldr = nullptr;
+    void *threshold_padded = nullptr;  // the allocation `threshold` lies in: VKR_STRIP_HALO_ROWS rows of the neighbouring strips above and below it
     uint64_t *coverage_buf = nullptr;  // light-volume masks, max_lights * tiles
     bool bloom1_valid = false, bloom2_valid = false;  // stored only by vkr_pass_bloom
 };
@@ -63,19 +64,28 @@ struct vkr_ctx {
     bool cubes_tiled = false;       // point shadow cubes are stored VKR_CUBE_LAYOUT_TILED_8X4_X25
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timing_valid = false;
+    // strips (vkr_strip_*): "this frame's composition pass is enqueued", "the neighbour's rows have arrived"
+    hipEvent_t ev_shaded = nullptr, ev_pulled = nullptr;
+    bool strip_shaded = false;
+    // RenderStage mirror (vkr_stage_*): what each stage's command buffer of the current frame holds
+    enum StageState { STAGE_INITIAL, STAGE_RECORDING, STAGE_IN_PASS, STAGE_PASS_ENDED, STAGE_EXECUTABLE };
+    struct Stage { StageState state = STAGE_INITIAL; bool cleared = false, drawn = false; };
+    Stage stages[VKR_STAGE_COUNT];
 };
 
 namespace vkr {
 
 static size_t rgba16f_bytes(int w, int h) { return (size_t)w * h * 8; }
+static size_t halo_bytes(const vkr_ctx *c) { return rgba16f_bytes(c->cfg.width, VKR_STRIP_HALO_ROWS); }
 static size_t cube_bytes(int n) { return (size_t)6 * n * n * 8; }
 
 static void free_frame_sized(vkr_ctx *c)
 {
     for (Frame &f : c->frames) {
         for (void *&g : f.gbuf) { if (g) (void)hipFree(g); g = nullptr; }
-        void **imgs[] = {&f.background, &f.color, &f.threshold, &f.bloom1, &f.bloom2, &f.ldr, (void **)&f.coverage_buf};
+        void **imgs[] = {&f.background, &f.color, &f.threshold_padded, &f.bloom1, &f.bloom2, &f.ldr, (void **)&f.coverage_buf};
         for (void **p : imgs) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        f.threshold = nullptr;
         f.has_background = false;
         f.bloom1_valid = f.bloom2_valid = false;
     }
@@ -88,7 +98,8 @@ static int32_t alloc_frame_sized(vkr_ctx *c)
         for (void *&g : f.gbuf) VKR_HIP_CHECK(hipMalloc(&g, img));
         VKR_HIP_CHECK(hipMalloc(&f.background, img));
         VKR_HIP_CHECK(hipMalloc(&f.color, img));
-        VKR_HIP_CHECK(hipMalloc(&f.threshold, img));
+        VKR_HIP_CHECK(hipMalloc(&f.threshold_padded, img + 2 * halo_bytes(c)));
+        f.threshold = (char *)f.threshold_padded + halo_bytes(c);
         VKR_HIP_CHECK(hipMalloc(&f.bloom1, img));
         VKR_HIP_CHECK(hipMalloc(&f.bloom2, img));
         VKR_HIP_CHECK(hipMalloc(&f.ldr, (size_t)c->cfg.width * c->cfg.height * 4));
@@ -112,8 +123,9 @@ static int32_t clear_frame_sized(vkr_ctx *c)
     for (Frame &f : c->frames) {
         int32_t rc = fill_u64(f.gbuf[0], px, 0ull, c->stream);
         for (int k = 1; k < 4 && rc == VKR_OK; k++) rc = fill_u64(f.gbuf[k], px, RGBA16F_0001, c->stream);
-        void *imgs[] = {f.background, f.color, f.threshold, f.bloom1, f.bloom2};
+        void *imgs[] = {f.background, f.color, f.bloom1, f.bloom2};
         for (void *img : imgs) if (rc == VKR_OK) rc = fill_u64(img, px, RGBA16F_0001, c->stream);
+        if (rc == VKR_OK) rc = fill_u64(f.threshold_padded, px + 2 * (size_t)c->cfg.width * VKR_STRIP_HALO_ROWS, RGBA16F_0001, c->stream);
         if (rc == VKR_OK) rc = fill_u64(f.ldr, px / 2, 0xFF000000FF000000ull, c->stream);
         if (rc != VKR_OK) return rc;
         if (px & 1) VKR_HIP_CHECK(hipMemsetAsync((char *)f.ldr + (px - 1) * 4, 0, 4, c->stream));
@@ -161,6 +173,8 @@ static void destroy(vkr_ctx *c)
     for (void *p : ibl) if (p) (void)hipFree(p);
     for (void *p : c->prefilter) if (p) (void)hipFree(p);
     for (hipEvent_t e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->ev_shaded) (void)hipEventDestroy(c->ev_shaded);
+    if (c->ev_pulled) (void)hipEventDestroy(c->ev_pulled);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -245,7 +259,7 @@ static int32_t run_geometry_pass(vkr_ctx *c, Frame &f)
     memset(&a, 0, sizeof(a));
     a.draws = draws.data(); a.n_draws = (int32_t)draws.size();
     a.scene = f.scene;
-    a.width = c->cfg.width; a.rows = c->cfg.height; a.frame_rows = c->cfg.height; a.row0 = 0;
+    a.width = c->cfg.width; a.rows = c->cfg.height; a.frame_rows = c->cfg.frame_rows; a.row0 = c->cfg.row0;
     a.albedo = f.gbuf[0]; a.normal = f.gbuf[1]; a.arm = f.gbuf[2]; a.position = f.gbuf[3];
     a.workspace = c->gp_workspace; a.workspace_bytes = c->gp_workspace_bytes;
     return vkr_gbuffer(&a, c->stream);
@@ -253,7 +267,7 @@ static int32_t run_geometry_pass(vkr_ctx *c, Frame &f)
 
 // The shadow render passes of EndFrame (VulkanRenderer.cs:325-376, 406-428) over the frame's draw calls.
 // Without draw calls the uploaded maps stay as they are.
-static int32_t run_shadow_passes(vkr_ctx *c, Frame &f)
+static int32_t run_point_shadows(vkr_ctx *c, Frame &f)
 {
     if (c->draw_calls.empty()) return VKR_OK;
     VkrPointShadowArgs ps;
@@ -263,14 +277,24 @@ static int32_t run_shadow_passes(vkr_ctx *c, Frame &f)
     ps.res = c->cfg.point_shadow_res; ps.far_plane = 25.0f;  // VulkanRenderer.cs:331
     ps.layout = c->cubes_tiled ? VKR_CUBE_LAYOUT_TILED_8X4_X25 : VKR_CUBE_LAYOUT_LINEAR;
     ps.out = f.cube_shadow;
-    int32_t rc = vkr_point_shadow_maps(&ps, c->stream);
-    if (rc != VKR_OK) return rc;
+    return vkr_point_shadow_maps(&ps, c->stream);
+}
+
+static int32_t run_dir_shadow(vkr_ctx *c, Frame &f)
+{
+    if (c->draw_calls.empty()) return VKR_OK;
     VkrDirShadowArgs ds;
     memset(&ds, 0, sizeof(ds));
-    ds.draws = ps.draws; ds.n_draws = ps.n_draws;
+    ds.draws = c->draw_calls.data(); ds.n_draws = (int32_t)c->draw_calls.size();
     memcpy(ds.light_space, f.scene.light_space_matrix, sizeof(ds.light_space));
     ds.res = c->cfg.dir_shadow_res; ds.out = f.dir_shadow;
     return vkr_dir_shadow_map(&ds, c->stream);
+}
+
+static int32_t run_shadow_passes(vkr_ctx *c, Frame &f)
+{
+    const int32_t rc = run_point_shadows(c, f);
+    return rc != VKR_OK ? rc : run_dir_shadow(c, f);
 }
 
 // The light-volume draws' coverage (what rasterising sphere.glb per light decides in the reference).
@@ -280,7 +304,7 @@ static int32_t run_coverage(vkr_ctx *c, Frame &f)
     if (!c->mesh_verts) return fail(VKR_ERR_ORDER, "VKR_COVERAGE_MESH needs a light-volume mesh: call vkr_set_light_volume_mesh first");
     VkrCoverageArgs a;
     memset(&a, 0, sizeof(a));
-    a.width = c->cfg.width; a.rows = c->cfg.height; a.frame_rows = c->cfg.height; a.row0 = 0;
+    a.width = c->cfg.width; a.rows = c->cfg.height; a.frame_rows = c->cfg.frame_rows; a.row0 = c->cfg.row0;
     a.scene = f.scene;
     a.lights = f.lights; a.n_lights = f.n_lights;
     a.verts = c->mesh_verts; a.n_verts = c->mesh_n_verts;
@@ -297,7 +321,7 @@ static int32_t run_skybox(vkr_ctx *c, Frame &f)
     if (!draws_skybox(c, f)) return VKR_OK;
     const void *env = c->env_tiled ? c->env_tiled : c->env;
     const int32_t layout = c->env_tiled ? VKR_ENV_LAYOUT_TILED_4X4 : VKR_ENV_LAYOUT_LINEAR;
-    return vkr_skybox(env, c->cfg.env_res, layout, &f.scene, c->cfg.width, c->cfg.height, c->cfg.height, 0, f.background, c->stream);
+    return vkr_skybox(env, c->cfg.env_res, layout, &f.scene, c->cfg.width, c->cfg.height, c->cfg.frame_rows, c->cfg.row0, f.background, c->stream);
 }
 
 static VkrBloomArgs bloom_args(vkr_ctx *c, Frame &f, int horizontal)
@@ -352,6 +376,9 @@ extern "C" int32_t vkr_create(const VkrConfig *config, vkr_ctx **out)
     if (cfg.brdf_lut_res == 0) cfg.brdf_lut_res = 512;
     if (cfg.frames_in_flight == 0) cfg.frames_in_flight = 2;
     VKR_REQUIRE(cfg.width > 0 && cfg.height > 0, "vkr_create: bad frame size %dx%d", cfg.width, cfg.height);
+    if (cfg.frame_rows == 0) { cfg.frame_rows = cfg.height; cfg.row0 = 0; }  // the context renders the whole frame
+    VKR_REQUIRE(cfg.row0 >= 0 && cfg.row0 + cfg.height <= cfg.frame_rows, "vkr_create: rows [%d,%d) lie outside a frame of %d rows", cfg.row0, cfg.row0 + cfg.height, cfg.frame_rows);
+    VKR_REQUIRE(cfg.frame_rows == cfg.height || cfg.height >= VKR_STRIP_HALO_ROWS, "vkr_create: a strip needs at least %d rows (got %d)", VKR_STRIP_HALO_ROWS, cfg.height);
     VKR_REQUIRE(cfg.max_lights > 0 && cfg.frames_in_flight > 0 && cfg.frames_in_flight <= 8, "vkr_create: bad max_lights / frames_in_flight");
     VKR_REQUIRE(cfg.dir_shadow_res > 0 && cfg.dir_shadow_res <= 32768 && cfg.point_shadow_res > 0 && cfg.point_shadow_res <= 8192, "vkr_create: bad shadow map size");
     VKR_REQUIRE(cfg.env_res > 0 && cfg.irradiance_res > 0 && cfg.prefilter_res > 0 && cfg.brdf_lut_res > 0, "vkr_create: bad IBL size");
@@ -371,6 +398,8 @@ extern "C" int32_t vkr_create(const VkrConfig *config, vkr_ctx **out)
     auto body = [&]() -> int32_t {
         VKR_HIP_CHECK(hipStreamCreate(&c->stream));
         for (hipEvent_t &e : c->ev) VKR_HIP_CHECK(hipEventCreate(&e));
+        VKR_HIP_CHECK(hipEventCreateWithFlags(&c->ev_shaded, hipEventDisableTiming));
+        VKR_HIP_CHECK(hipEventCreateWithFlags(&c->ev_pulled, hipEventDisableTiming));
         int32_t r = alloc_frame_sized(c);
         if (r != VKR_OK) return r;
         for (Frame &f : c->frames) {
@@ -402,18 +431,27 @@ extern "C" int32_t vkr_destroy(vkr_ctx *ctx)
     return VKR_OK;
 }
 
-extern "C" int32_t vkr_resize(vkr_ctx *c, int32_t width, int32_t height)
+extern "C" int32_t vkr_resize_strip(vkr_ctx *c, int32_t width, int32_t height, int32_t frame_rows, int32_t row0)
 {
     VKR_CTX(c);
     VKR_REQUIRE(width > 0 && height > 0, "vkr_resize: bad size %dx%d", width, height);
+    VKR_REQUIRE(row0 >= 0 && row0 + height <= frame_rows, "vkr_resize: rows [%d,%d) lie outside a frame of %d rows", row0, row0 + height, frame_rows);
+    VKR_REQUIRE(frame_rows == height || height >= VKR_STRIP_HALO_ROWS, "vkr_resize: a strip needs at least %d rows (got %d)", VKR_STRIP_HALO_ROWS, height);
     VKR_REQUIRE(!c->in_frame, "vkr_resize: called between BeginFrame and EndFrame");
     VKR_HIP_CHECK(hipStreamSynchronize(c->stream));
     free_frame_sized(c);
-    c->cfg.width = width; c->cfg.height = height;
+    c->cfg.width = width; c->cfg.height = height; c->cfg.frame_rows = frame_rows; c->cfg.row0 = row0;
     c->timing_valid = false;
     if (c->gp_workspace) { (void)hipFree(c->gp_workspace); c->gp_workspace = nullptr; }
     int32_t rc = alloc_frame_sized(c);
     return rc == VKR_OK ? clear_frame_sized(c) : rc;
+}
+
+extern "C" int32_t vkr_resize(vkr_ctx *c, int32_t width, int32_t height)
+{
+    VKR_REQUIRE(c != nullptr, "vkr_resize: context is null");
+    VKR_REQUIRE(c->cfg.frame_rows == c->cfg.height, "vkr_resize: the context renders a strip of a frame; use vkr_resize_strip");
+    return vkr_resize_strip(c, width, height, height, 0);
 }
 
 extern "C" int32_t vkr_update_scene_info(vkr_ctx *c, const VkrSceneInfo *info)
@@ -445,8 +483,10 @@ extern "C" int32_t vkr_begin_frame(vkr_ctx *c)
     VKR_CTX(c);
     if (c->in_frame) return fail(VKR_ERR_ORDER, "Tried to begin frame before previous frame was finished!");  // VulkanRenderer.cs:288
     c->in_frame = true;
+    c->strip_shaded = false;
     c->draw_calls.clear();  // VulkanRenderer.cs:316
     c->draw_mesh.clear(); c->draw_material.clear();
+    for (vkr_ctx::Stage &st : c->stages) st = vkr_ctx::Stage();  // ResetCommandBuffer of every stage, VulkanRenderer.cs:307-314
     return VKR_OK;
 }
 
@@ -710,10 +750,190 @@ extern "C" int32_t vkr_pass_postprocess(vkr_ctx *c)
     return vkr_postprocess(f.color, f.bloom2, f.ldr, c->cfg.width, c->cfg.height, c->cfg.flags & VKR_POST_SRGB_TARGET, c->stream);
 }
 
-extern "C" int32_t vkr_end_frame(vkr_ctx *c)
+// ---- RenderStage mirror --------------------------------------------------------------------------------------
+// The reference records every pass of a frame into a RenderStage (RenderStage.cs:99-190: BeginCommands,
+// BeginRenderPass, the draws, EndRenderPass, EndCommands) and submits the command buffers at the end of EndFrame
+// (VulkanRenderer.cs:559-595).  Here a stage remembers what was recorded; vkr_submit_frame runs the recorded
+// stages on the context's stream in the reference's submission order.
+
+static const char *const STAGE_NAMES[VKR_STAGE_COUNT] = {"point shadow", "geometry", "directional shadow", "composition", "bloom 1", "bloom 2", "post-process"};
+
+static int32_t stage_of(vkr_ctx *c, int32_t stage, int32_t frame, const char *fn, vkr_ctx::Stage **out)
+{
+    if (stage < 0 || stage >= VKR_STAGE_COUNT) return fail(VKR_ERR_INVALID, "%s: unknown stage %d", fn, stage);
+    if (frame != c->frame) return fail(VKR_ERR_INVALID, "%s: command buffer %d is not the current frame's (%d)", fn, frame, c->frame);
+    *out = &c->stages[stage];
+    return VKR_OK;
+}
+
+extern "C" int32_t vkr_stage_reset_commands(vkr_ctx *c, int32_t stage, int32_t frame)
+{
+    VKR_CTX(c);
+    vkr_ctx::Stage *st;
+    int32_t rc = stage_of(c, stage, frame, __func__, &st);
+    if (rc != VKR_OK) return rc;
+    *st = vkr_ctx::Stage();
+    return VKR_OK;
+}
+
+extern "C" int32_t vkr_stage_begin_commands(vkr_ctx *c, int32_t stage, int32_t frame)
+{
+    VKR_CTX(c);
+    vkr_ctx::Stage *st;
+    int32_t rc = stage_of(c, stage, frame, __func__, &st);
+    if (rc != VKR_OK) return rc;
+    if (st->state != vkr_ctx::STAGE_INITIAL && st->state != vkr_ctx::STAGE_EXECUTABLE)
+        return fail(VKR_ERR_ORDER, "Failed to begin command buffer! (the %s stage is already recording)", STAGE_NAMES[stage]);  // RenderStage.cs:108
+    *st = vkr_ctx::Stage();  // beginning an executable command buffer resets it
+    st->state = vkr_ctx::STAGE_RECORDING;
+    return VKR_OK;
+}
+
+extern "C" int32_t vkr_stage_begin_render_pass(vkr_ctx *c, int32_t stage, int32_t frame)
+{
+    VKR_CTX(c);
+    vkr_ctx::Stage *st;
+    int32_t rc = stage_of(c, stage, frame, __func__, &st);
+    if (rc != VKR_OK) return rc;
+    if (st->state != vkr_ctx::STAGE_RECORDING)
+        return fail(VKR_ERR_ORDER, "vkr_stage_begin_render_pass: the %s stage is not recording (BeginCommands first, one render pass per command buffer)", STAGE_NAMES[stage]);
+    st->state = vkr_ctx::STAGE_IN_PASS;
+    st->cleared = true;  // every attachment of the reference's passes is loaded with its clear value
+    return VKR_OK;
+}
+
+extern "C" int32_t vkr_stage_draw(vkr_ctx *c, int32_t stage, int32_t frame)
+{
+    VKR_CTX(c);
+    vkr_ctx::Stage *st;
+    int32_t rc = stage_of(c, stage, frame, __func__, &st);
+    if (rc != VKR_OK) return rc;
+    if (st->state != vkr_ctx::STAGE_IN_PASS)
+        return fail(VKR_ERR_ORDER, "vkr_stage_draw: the %s stage is not inside a render pass", STAGE_NAMES[stage]);
+    st->drawn = true;
+    return VKR_OK;
+}
+
+extern "C" int32_t vkr_stage_end_render_pass(vkr_ctx *c, int32_t stage, int32_t frame)
+{
+    VKR_CTX(c);
+    vkr_ctx::Stage *st;
+    int32_t rc = stage_of(c, stage, frame, __func__, &st);
+    if (rc != VKR_OK) return rc;
+    if (st->state != vkr_ctx::STAGE_IN_PASS)
+        return fail(VKR_ERR_ORDER, "vkr_stage_end_render_pass: the %s stage is not inside a render pass", STAGE_NAMES[stage]);
+    st->state = vkr_ctx::STAGE_PASS_ENDED;
+    return VKR_OK;
+}
+
+extern "C" int32_t vkr_stage_end_commands(vkr_ctx *c, int32_t stage, int32_t frame)
+{
+    VKR_CTX(c);
+    vkr_ctx::Stage *st;
+    int32_t rc = stage_of(c, stage, frame, __func__, &st);
+    if (rc != VKR_OK) return rc;
+    if (st->state != vkr_ctx::STAGE_RECORDING && st->state != vkr_ctx::STAGE_PASS_ENDED)
+        return fail(VKR_ERR_ORDER, "Failed to end command buffer! (the %s stage is %s)", STAGE_NAMES[stage],  // RenderStage.cs:120
+                    st->state == vkr_ctx::STAGE_IN_PASS ? "inside a render pass" : "not recording");
+    st->state = vkr_ctx::STAGE_EXECUTABLE;
+    return VKR_OK;
+}
+
+// A render pass that was begun and ended without draws leaves its attachments at their clear values.
+static int32_t clear_stage_attachments(vkr_ctx *c, Frame &f, int32_t stage)
+{
+    const size_t px = (size_t)c->cfg.width * c->cfg.height;
+    int32_t rc = VKR_OK;
+    switch (stage) {
+    case VKR_STAGE_POINT_SHADOW: {
+        const size_t cube = (size_t)c->cfg.max_lights * 6 * c->cfg.point_shadow_res * c->cfg.point_shadow_res;  // even: 6 faces
+        return fill_u64(f.cube_shadow, cube / 2, c->cubes_tiled ? D32F_25_PAIR : D32F_ONE_PAIR, c->stream);
+    }
+    case VKR_STAGE_DIR_SHADOW: {
+        const size_t dir = (size_t)c->cfg.dir_shadow_res * c->cfg.dir_shadow_res;
+        rc = fill_u64(f.dir_shadow, dir / 2, D32F_ONE_PAIR, c->stream);
+        const float one = 1.0f;
+        if (rc == VKR_OK && (dir & 1)) VKR_HIP_CHECK(hipMemcpyAsync(f.dir_shadow + dir - 1, &one, 4, hipMemcpyHostToDevice, c->stream));
+        return rc;
+    }
+    case VKR_STAGE_GEOMETRY:
+        rc = fill_u64(f.gbuf[0], px, 0ull, c->stream);
+        for (int k = 1; k < 4 && rc == VKR_OK; k++) rc = fill_u64(f.gbuf[k], px, RGBA16F_0001, c->stream);
+        return rc;
+    case VKR_STAGE_COMPOSITION:
+        rc = fill_u64(f.color, px, RGBA16F_0001, c->stream);
+        return rc != VKR_OK ? rc : fill_u64(f.threshold, px, RGBA16F_0001, c->stream);
+    case VKR_STAGE_BLOOM1: f.bloom1_valid = true; return fill_u64(f.bloom1, px, RGBA16F_0001, c->stream);
+    case VKR_STAGE_BLOOM2: f.bloom2_valid = true; return fill_u64(f.bloom2, px, RGBA16F_0001, c->stream);
+    default:
+        rc = fill_u64(f.ldr, px / 2, 0xFF000000FF000000ull, c->stream);
+        if (rc == VKR_OK && (px & 1)) VKR_HIP_CHECK(hipMemsetAsync((char *)f.ldr + (px - 1) * 4, 0, 4, c->stream));
+        return rc;
+    }
+}
+
+static int32_t run_stage(vkr_ctx *c, Frame &f, int32_t stage)
+{
+    int32_t rc;
+    switch (stage) {
+    case VKR_STAGE_POINT_SHADOW: return run_point_shadows(c, f);
+    case VKR_STAGE_GEOMETRY: return run_geometry_pass(c, f);
+    case VKR_STAGE_DIR_SHADOW: return run_dir_shadow(c, f);
+    case VKR_STAGE_COMPOSITION: {  // skybox draw, composition draw, one light-volume draw per light
+        VkrShadeArgs a;
+        if ((rc = fill_shade_args(c, f, a)) != VKR_OK) return rc;
+        if ((rc = run_coverage(c, f)) != VKR_OK) return rc;
+        if ((rc = run_skybox(c, f)) != VKR_OK) return rc;
+        return vkr_shade(&a, c->stream);
+    }
+    case VKR_STAGE_BLOOM1: return vkr_pass_bloom(c, 1);
+    case VKR_STAGE_BLOOM2: return vkr_pass_bloom(c, 0);
+    default: return vkr_pass_postprocess(c);
+    }
+}
+
+extern "C" int32_t vkr_submit_frame(vkr_ctx *c)
 {
     VKR_CTX(c);
     if (!c->in_frame) return fail(VKR_ERR_ORDER, "Tried to end frame before beginning a new one!");  // VulkanRenderer.cs:322
+    if (c->cfg.frame_rows != c->cfg.height) return fail(VKR_ERR_UNSUPPORTED, "vkr_submit_frame: stage recording is for contexts that render a whole frame; a strip ends its frame with vkr_strip_shade / vkr_strip_finish");
+    Frame &f = c->frames[c->frame];
+    for (int s = 0; s < VKR_STAGE_COUNT; s++)
+        if (c->stages[s].state != vkr_ctx::STAGE_INITIAL && c->stages[s].state != vkr_ctx::STAGE_EXECUTABLE)
+            return fail(VKR_ERR_ORDER, "Unable to submit graphics queue: the %s stage is still recording", STAGE_NAMES[s]);  // VulkanRenderer.cs:593
+    // the stages are numbered in the reference's submission order (VulkanRenderer.cs:563-584)
+    for (int s = 0; s < VKR_STAGE_COUNT; s++) {
+        const vkr_ctx::Stage &st = c->stages[s];
+        if (st.state != vkr_ctx::STAGE_EXECUTABLE || !st.cleared) continue;  // nothing recorded: the stage's images stay as they are
+        const int32_t rc = st.drawn ? run_stage(c, f, s) : clear_stage_attachments(c, f, s);
+        if (rc != VKR_OK) return rc;
+    }
+    c->timing_valid = false;
+    c->in_frame = false;
+    c->frame = (c->frame + 1) % c->cfg.frames_in_flight;  // VulkanRenderer.cs:622
+    return VKR_OK;
+}
+
+// ---- strips: a context that owns rows [row0, row0 + height) of a frame ---------------------------------------
+
+extern "C" int32_t vkr_strip_plan(int32_t frame_rows, int32_t n_strips, int32_t k, int32_t *row0, int32_t *rows)
+{
+    VKR_REQUIRE(row0 && rows, "vkr_strip_plan: null output");
+    VKR_REQUIRE(n_strips > 0 && k >= 0 && k < n_strips, "vkr_strip_plan: strip %d of %d", k, n_strips);
+    const int32_t base = frame_rows / n_strips, extra = frame_rows % n_strips;  // the first `extra` strips are one row taller
+    VKR_REQUIRE(n_strips == 1 ? frame_rows > 0 : base >= VKR_STRIP_HALO_ROWS, "vkr_strip_plan: %d rows over %d strips leaves strips of fewer than %d rows", frame_rows, n_strips, VKR_STRIP_HALO_ROWS);
+    *row0 = k * base + (k < extra ? k : extra);
+    *rows = base + (k < extra ? 1 : 0);
+    return VKR_OK;
+}
+
+static bool has_neighbour(const vkr_ctx *c, int side) { return side == 0 ? c->cfg.row0 > 0 : c->cfg.row0 + c->cfg.height < c->cfg.frame_rows; }
+
+extern "C" int32_t vkr_strip_shade(vkr_ctx *c)
+{
+    VKR_CTX(c);
+    if (!c->in_frame) return fail(VKR_ERR_ORDER, "Tried to end frame before beginning a new one!");  // VulkanRenderer.cs:322
+    if (c->strip_shaded) return fail(VKR_ERR_ORDER, "vkr_strip_shade: this frame's composition pass is already enqueued; vkr_strip_finish comes next");
     Frame &f = c->frames[c->frame];
     VkrShadeArgs a;
     int32_t rc = fill_shade_args(c, f, a);
@@ -725,22 +945,99 @@ extern "C" int32_t vkr_end_frame(vkr_ctx *c)
     if ((rc = run_skybox(c, f)) != VKR_OK) return rc;
     if ((rc = vkr_shade(&a, c->stream)) != VKR_OK) return rc;
     VKR_HIP_CHECK(hipEventRecord(c->ev[1], c->stream));
+    VKR_HIP_CHECK(hipEventRecord(c->ev_shaded, c->stream));
+    c->strip_shaded = true;
+    return VKR_OK;
+}
+
+extern "C" int32_t vkr_strip_halo(vkr_ctx *c, int32_t side, const void **send, void **recv, int64_t *bytes)
+{
+    VKR_CTX(c);
+    VKR_REQUIRE(side == VKR_STRIP_ABOVE || side == VKR_STRIP_BELOW, "vkr_strip_halo: side %d", side);
+    VKR_REQUIRE(has_neighbour(c, side), "vkr_strip_halo: the strip has no neighbour %s it (it touches the frame edge)", side == VKR_STRIP_ABOVE ? "above" : "below");
+    Frame &f = c->frames[c->frame];
+    const size_t hb = halo_bytes(c), rows_b = rgba16f_bytes(c->cfg.width, c->cfg.height);
+    char *base = (char *)f.threshold_padded;
+    if (send) *send = side == VKR_STRIP_ABOVE ? base + hb : base + rows_b;        // the strip's first / last rows
+    if (recv) *recv = side == VKR_STRIP_ABOVE ? base : base + hb + rows_b;         // the rows beyond them
+    if (bytes) *bytes = (int64_t)hb;
+    return VKR_OK;
+}
+
+extern "C" int32_t vkr_strip_exchange(vkr_ctx *upper, vkr_ctx *lower)
+{
+    VKR_REQUIRE(upper && lower && upper != lower, "vkr_strip_exchange: two different contexts are needed");
+    VKR_REQUIRE(upper->cfg.width == lower->cfg.width && upper->cfg.frame_rows == lower->cfg.frame_rows &&
+                upper->cfg.row0 + upper->cfg.height == lower->cfg.row0,
+                "vkr_strip_exchange: rows [%d,%d) and [%d,%d) of frames %d / %d rows tall, %d / %d wide are not neighbouring strips of one frame",
+                upper->cfg.row0, upper->cfg.row0 + upper->cfg.height, lower->cfg.row0, lower->cfg.row0 + lower->cfg.height,
+                upper->cfg.frame_rows, lower->cfg.frame_rows, upper->cfg.width, lower->cfg.width);
+    if (!upper->strip_shaded || !lower->strip_shaded) return fail(VKR_ERR_ORDER, "vkr_strip_exchange: both strips need vkr_strip_shade for the frame first");
+    const void *up_send, *lo_send;
+    void *up_recv, *lo_recv;
+    int64_t bytes = 0;
+    int32_t rc = vkr_strip_halo(upper, VKR_STRIP_BELOW, &up_send, &up_recv, &bytes);
+    if (rc == VKR_OK) rc = vkr_strip_halo(lower, VKR_STRIP_ABOVE, &lo_send, &lo_recv, &bytes);
+    if (rc != VKR_OK) return rc;
+    const int du = upper->cfg.device, dl = lower->cfg.device;
+    if (du != dl) {  // direct copies over xGMI where the devices allow it; otherwise the runtime stages them
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, dl, du) == hipSuccess && can) { VKR_HIP_CHECK(hipSetDevice(dl)); (void)hipDeviceEnablePeerAccess(du, 0); (void)hipGetLastError(); }
+        if (hipDeviceCanAccessPeer(&can, du, dl) == hipSuccess && can) { VKR_HIP_CHECK(hipSetDevice(du)); (void)hipDeviceEnablePeerAccess(dl, 0); (void)hipGetLastError(); }
+    }
+    // each strip pulls its neighbour's rows on its own stream once the neighbour's composition pass is done ...
+    VKR_HIP_CHECK(hipSetDevice(dl));
+    VKR_HIP_CHECK(hipStreamWaitEvent(lower->stream, upper->ev_shaded, 0));
+    VKR_HIP_CHECK(hipMemcpyPeerAsync(lo_recv, dl, up_send, du, (size_t)bytes, lower->stream));
+    VKR_HIP_CHECK(hipEventRecord(lower->ev_pulled, lower->stream));
+    VKR_HIP_CHECK(hipSetDevice(du));
+    VKR_HIP_CHECK(hipStreamWaitEvent(upper->stream, lower->ev_shaded, 0));
+    VKR_HIP_CHECK(hipMemcpyPeerAsync(up_recv, du, lo_send, dl, (size_t)bytes, upper->stream));
+    VKR_HIP_CHECK(hipEventRecord(upper->ev_pulled, upper->stream));
+    // ... and neither goes on (and later overwrites the rows it lent) before the other has them
+    VKR_HIP_CHECK(hipStreamWaitEvent(upper->stream, lower->ev_pulled, 0));
+    VKR_HIP_CHECK(hipSetDevice(dl));
+    VKR_HIP_CHECK(hipStreamWaitEvent(lower->stream, upper->ev_pulled, 0));
+    return VKR_OK;
+}
+
+extern "C" int32_t vkr_strip_finish(vkr_ctx *c)
+{
+    VKR_CTX(c);
+    if (!c->in_frame || !c->strip_shaded) return fail(VKR_ERR_ORDER, "vkr_strip_finish: vkr_strip_shade has not run for this frame");
+    Frame &f = c->frames[c->frame];
     VKR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
-    // both bloom passes and the post-process draw run as one kernel; neither bloom image is stored
+    // both bloom passes and the post-process draw run as one kernel; neither bloom image is stored.  The source is
+    // the thresholded image with the neighbours' rows around it: the frame's edges clamp, the strip's edges do not.
+    const int H = VKR_STRIP_HALO_ROWS;
     VkrBloomChainArgs bc;
     memset(&bc, 0, sizeof(bc));
-    bc.threshold = f.threshold; bc.hdr = f.color; bc.out_rgba8 = f.ldr;
-    bc.width = c->cfg.width; bc.rows = c->cfg.height; bc.src_rows = c->cfg.height; bc.src_row_offset = 0;
+    bc.threshold = f.threshold_padded; bc.hdr = f.color; bc.out_rgba8 = f.ldr;
+    bc.width = c->cfg.width; bc.rows = c->cfg.height; bc.src_rows = c->cfg.height + 2 * H; bc.src_row_offset = H;
     bc.wrap_h = VKR_WRAP_REPEAT; bc.clamp_lo_h = 0; bc.clamp_hi_h = c->cfg.width - 1;   // textureSampler along x
-    bc.wrap_v = VKR_WRAP_CLAMP; bc.clamp_lo_v = 0; bc.clamp_hi_v = c->cfg.height - 1;   // bloomSampler along y
+    bc.wrap_v = VKR_WRAP_CLAMP;                                                          // bloomSampler along y
+    bc.clamp_lo_v = has_neighbour(c, VKR_STRIP_ABOVE) ? 0 : H;
+    bc.clamp_hi_v = has_neighbour(c, VKR_STRIP_BELOW) ? c->cfg.height + 2 * H - 1 : H + c->cfg.height - 1;
     bc.flags = c->cfg.flags & VKR_POST_SRGB_TARGET;
-    if ((rc = vkr_bloom_postprocess(&bc, c->stream)) != VKR_OK) return rc;
+    int32_t rc = vkr_bloom_postprocess(&bc, c->stream);
+    if (rc != VKR_OK) return rc;
     VKR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
     f.bloom1_valid = f.bloom2_valid = false;
     c->timing_valid = true;
+    c->strip_shaded = false;
     c->in_frame = false;
     c->frame = (c->frame + 1) % c->cfg.frames_in_flight;  // VulkanRenderer.cs:622
     return VKR_OK;
+}
+
+extern "C" int32_t vkr_end_frame(vkr_ctx *c)
+{
+    VKR_CTX(c);
+    if (!c->in_frame) return fail(VKR_ERR_ORDER, "Tried to end frame before beginning a new one!");  // VulkanRenderer.cs:322
+    if (c->cfg.frame_rows != c->cfg.height)
+        return fail(VKR_ERR_ORDER, "vkr_end_frame: the context renders a strip of a frame: vkr_strip_shade, the halo rows, then vkr_strip_finish");
+    const int32_t rc = vkr_strip_shade(c);
+    return rc != VKR_OK ? rc : vkr_strip_finish(c);
 }
 
 extern "C" int32_t vkr_read(vkr_ctx *c, int32_t frame, int32_t target, int32_t mip, void *host, int64_t host_bytes)

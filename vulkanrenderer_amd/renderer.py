@@ -59,13 +59,16 @@ class HipRenderer:
 
     def __init__(self, width: int = 1920, height: int = 1080, *, device: int = 0, max_lights: int = 0,
                  dir_shadow_res: int = 0, point_shadow_res: int = 0, env_res: int = 0, irradiance_res: int = 0,
-                 prefilter_res: int = 0, prefilter_mips: int = 0, brdf_lut_res: int = 0, srgb_target: bool = False):
+                 prefilter_res: int = 0, prefilter_mips: int = 0, brdf_lut_res: int = 0, srgb_target: bool = False,
+                 frame_rows: int = 0, row0: int = 0):
+        """`frame_rows` / `row0`: the renderer owns rows [row0, row0 + height) of a frame of frame_rows rows (one
+        strip of a frame rendered on several GPUs: StripShade / strip_exchange / StripFinish end its frames)."""
         self._lib = _lib.load()
         cfg = _lib.Config(device=device, width=width, height=height, max_lights=max_lights,
                           dir_shadow_res=dir_shadow_res, point_shadow_res=point_shadow_res, env_res=env_res,
                           irradiance_res=irradiance_res, prefilter_res=prefilter_res, prefilter_mips=prefilter_mips,
                           brdf_lut_res=brdf_lut_res, frames_in_flight=self.MaxFramesInFlight,
-                          flags=_lib.POST_SRGB_TARGET if srgb_target else 0)
+                          flags=_lib.POST_SRGB_TARGET if srgb_target else 0, frame_rows=frame_rows, row0=row0)
         self._ctx = C.c_void_p()
         _lib.check(self._lib.vkr_create(C.byref(cfg), C.byref(self._ctx)))
         self.width, self.height = width, height
@@ -235,7 +238,41 @@ class HipRenderer:
     def CreateBRDFLUTTexture(self) -> None:
         self._call(self._lib.vkr_create_brdf_lut)
 
-    # ---- single passes (RenderStage's begin / draw / end shape collapses to one call each) ------
+    # ---- strips: one frame on several GPUs ----------------------------------------------------------
+    def StripShade(self) -> None:
+        """Every pass of the frame up to the composition pass, for this renderer's rows."""
+        self._set_lights()
+        self._call(self._lib.vkr_strip_shade)
+
+    def StripFinish(self) -> None:
+        """Bloom 1, bloom 2 and post-process for this renderer's rows (after the halo rows of the neighbouring
+        strips have arrived: strip_exchange); advances the frame index."""
+        self._call(self._lib.vkr_strip_finish)
+        self._explicit_lights = False
+
+    def StripHalo(self, side: int) -> tuple[int, int, int]:
+        """Device addresses (send from, receive into) and size in bytes of the rows this strip swaps with its
+        neighbour on `side` (_lib.STRIP_ABOVE / STRIP_BELOW), for hosts that move them with a transport of their own."""
+        send, recv, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        self._call(self._lib.vkr_strip_halo, side, C.byref(send), C.byref(recv), C.byref(n))
+        return send.value, recv.value, n.value
+
+    # ---- RenderStage mirror (RenderStage.cs:99-190) -----------------------------------------------
+    def Stage(self, stage: int) -> "HipRenderStage":
+        """The reference's stage object for _lib.STAGE_*: record with its five calls, run with SubmitFrame()."""
+        return HipRenderStage(self, stage)
+
+    def PushLights(self) -> None:
+        """What EndFrame does before its stages: the light records of the frame go to the device."""
+        self._set_lights()
+
+    def SubmitFrame(self) -> None:
+        """Runs the recorded stages in the reference's submission order (VulkanRenderer.cs:559-595) and advances
+        the frame index (:622)."""
+        self._call(self._lib.vkr_submit_frame)
+        self._explicit_lights = False
+
+    # ---- single passes, run at once ----------------------------------------------------------------
     def CompositionPass(self) -> None:
         self._set_lights()
         self._call(self._lib.vkr_pass_composition)
@@ -270,3 +307,44 @@ class HipRenderer:
         t = _lib.Timing()
         self._call(self._lib.vkr_get_timing, C.byref(t))
         return {"shade_ms": t.shade_ms, "bloom_h_ms": t.bloom_h_ms, "bloom_v_post_ms": t.bloom_v_post_ms, "frame_ms": t.frame_ms}
+
+
+def strip_plan(frame_rows: int, n_strips: int, k: int) -> tuple[int, int]:
+    """(row0, rows) of strip k when a frame of frame_rows rows is cut into n_strips near-equal strips."""
+    row0, rows = C.c_int32(), C.c_int32()
+    _lib.check(_lib.load().vkr_strip_plan(frame_rows, n_strips, k, C.byref(row0), C.byref(rows)))
+    return row0.value, rows.value
+
+
+def strip_exchange(upper: HipRenderer, lower: HipRenderer) -> None:
+    """Swaps the boundary rows of two neighbouring strips of one process (device-to-device, asynchronous)."""
+    _lib.check(upper._lib.vkr_strip_exchange(upper._ctx, lower._ctx))
+
+
+class HipRenderStage:
+    """RenderStage.cs:99-190 over the C ABI: the reference's five calls with their arguments (commandBufferIndex is
+    the current frame), plus Draw() for the draws VulkanRenderer.EndFrame records into the stage."""
+
+    def __init__(self, renderer: HipRenderer, stage: int):
+        self._r, self._stage = renderer, stage
+
+    def _do(self, fn, command_buffer_index: int) -> None:
+        self._r._call(fn, self._stage, command_buffer_index)
+
+    def ResetCommandBuffer(self, commandBufferIndex: int) -> None:
+        self._do(self._r._lib.vkr_stage_reset_commands, commandBufferIndex)
+
+    def BeginCommands(self, commandBufferIndex: int) -> None:
+        self._do(self._r._lib.vkr_stage_begin_commands, commandBufferIndex)
+
+    def BeginRenderPass(self, commandBufferIndex: int, framebufferIndex: int) -> None:
+        self._do(self._r._lib.vkr_stage_begin_render_pass, commandBufferIndex)
+
+    def Draw(self, commandBufferIndex: int) -> None:
+        self._do(self._r._lib.vkr_stage_draw, commandBufferIndex)
+
+    def EndRenderPass(self, commandBufferIndex: int) -> None:
+        self._do(self._r._lib.vkr_stage_end_render_pass, commandBufferIndex)
+
+    def EndCommands(self, commandBufferIndex: int) -> None:
+        self._do(self._r._lib.vkr_stage_end_commands, commandBufferIndex)
