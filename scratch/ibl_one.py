@@ -13,8 +13,9 @@ irr = torch.empty((6, 64, 64, 4), dtype=torch.float16, device=dev)
 pres = [torch.empty((6, 128 >> m, 128 >> m, 4), dtype=torch.float16, device=dev) for m in range(5)]
 lut = torch.empty((512, 512, 2), dtype=torch.float16, device=dev)
 P.equirect_to_cube(src, _lib.SRC_RGBA16F, env)
-P.irradiance(env, irr, _lib.IRRADIANCE_SEQUENTIAL)
-for m in range(2):
-    P.prefilter(env, pres[m], m / 4.0)
+tiled = P.tile_env_cube(env)  # the copy in 4x4-texel tiles that the two sampling passes read
+P.irradiance(tiled, irr, _lib.IRRADIANCE_SEQUENTIAL, env_layout=_lib.ENV_LAYOUT_TILED_4X4)
+for m in range(5):
+    P.prefilter(tiled, pres[m], m / 4.0, env_layout=_lib.ENV_LAYOUT_TILED_4X4)
 P.brdf_lut(lut)
 torch.cuda.synchronize()

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const float *table, const u
 int main()
 {
     const int blocks = 256 * 8, threads = blocks * 256;  // 8 blocks x 4 waves = 32 waves per CU
-    const size_t table_bytes = 64u << 20;
+    const size_t table_bytes = 256u << 20;  // the largest pattern: the size class of a 2048^2 RGBA16F cube (201 MB), most of the 256 MiB Infinity Cache
     float *table; unsigned *offs; float *out;
     CHECK(hipMalloc(&table, table_bytes));
     CHECK(hipMemset(table, 0, table_bytes));
@@ -63,7 +63,8 @@ int main()
     Pattern pats[] = {{"coalesced row", 0, (16u << 10) - 1}, {"8 rows x 8 dwords, 16 KiB table", 1, (16u << 10) - 1},
                       {"4 rows x 16 dwords, 16 KiB table", 3, (16u << 10) - 1},
                       {"8 rows x 8 dwords, 4 MiB table", 1, (4u << 20) - 1}, {"random lines, 16 KiB table", 2, (16u << 10) - 1},
-                      {"random lines, 2 MiB table", 2, (2u << 20) - 1}, {"random lines, 64 MiB table", 2, (64u << 20) - 1}};
+                      {"random lines, 2 MiB table", 2, (2u << 20) - 1}, {"random lines, 64 MiB table", 2, (64u << 20) - 1},
+                      {"random lines, 256 MiB table", 2, (256u << 20) - 1}};
     for (auto &pt : pats) {
         srand(1);
         for (int k = 0; k < 8; k++)
@@ -99,6 +100,8 @@ int main()
             CHECK(hipEventElapsedTime(&ms, e0, e1));
             double instr_per_cu = (double)blocks * 4 * ITER * 8 / 256.0;
             printf("  m%d %6.1f cyc", mode, ms * 1e-3 * 2.4e9 / instr_per_cu);
+            // every lane of a random-line gather brings in its own 128-byte line
+            if (pt.kind == 2 && mode == 0) printf(" (%.2f TB/s of lines)", (double)blocks * 4 * ITER * 8 * 64 * 128 / (ms * 1e-3) / 1e12);
         }
         printf("\n");
     }

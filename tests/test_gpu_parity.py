@@ -45,6 +45,8 @@ FRAMES = [
     (13, 64, 64, 0, 16, 64),       # no point lights at all
     (14, 96, 80, 33, 16, 64),      # more lights than the reference's MaxLights
     (16, 88, 48, 2, 24, 64),       # cube faces whose size is not a power of two
+    (17, 72, 40, 100, 8, 64),      # enough lights for two launches (64 + 36): the second continues from the stored targets
+    (18, 56, 24, 161, 8, 32),      # three launches (64 + 97 would exceed a launch and a half: 64 + 64 + 33 lights)
 ]
 
 

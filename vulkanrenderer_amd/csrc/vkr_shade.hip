@@ -27,6 +27,7 @@ struct ShadeParams {
     const uint2 *albedo, *normal, *arm, *position, *background;
     const float *lights;  // VkrLightInfo array viewed as floats, 23 floats per light
     int n_lights;
+    int light_begin, light_end;  // the lights this launch draws; a launch with light_begin > 0 continues from the stored targets
     const float *dir_shadow; int dir_res;
     const float *cube_shadow; int cube_res;
     const void *irradiance; int irr_res;
@@ -352,24 +353,34 @@ VKR_DEV int wave_common_face(float fx, float fy, float fz, float r)
     return neg == 0ull ? axis : (neg == active ? axis + 1 : -1);
 }
 
-// Workgroups are dealt to the 8 XCDs round-robin by id, and each XCD has its own L2.  This maps
-// block id -> tile so that each XCD shades one contiguous run of tiles, ordered in 64-tile-wide
-// (512-pixel) column blocks: the workgroups resident on an XCD at one time cover a compact screen region and
-// therefore a compact region of every shadow map, which keeps their shared texels in that L2.
-VKR_DEV void tile_of_block(unsigned b, int tiles_x, int tiles_y, int &tx, int &ty)
+// Workgroups are dealt to the 8 XCDs round-robin by id, and each XCD has its own L2.  This maps block id -> tile so
+// that the workgroups resident on an XCD at one time cover a compact screen region, and therefore a compact region
+// of every shadow map, which keeps their shared texels in that L2: tiles are ordered in 64-tile-wide (512-pixel)
+// column blocks, row-major inside a block, the order is cut into runs of SHADE_RUN tiles, and the runs are dealt to
+// the XCDs in turn.  An XCD's share is thus spread over the whole frame in small pieces: every XCD gets the same mix
+// of cheap (background, back-facing) and expensive tiles and they finish together -- with one contiguous eighth of the
+// frame per XCD the slowest eighth set the time of a 4K launch, 10 % above the time per pixel of larger frames.
+// Returns false for the ids past the last tile (the grid is rounded up to whole rounds of 8 runs).
+#ifndef VKR_SHADE_RUN
+#define VKR_SHADE_RUN 256
+#endif
+static constexpr unsigned SHADE_RUN = VKR_SHADE_RUN;
+static constexpr int SHADE_LIGHTS_PER_LAUNCH = 64;  // see vkr_shade
+
+VKR_DEV bool tile_of_block(unsigned b, int tiles_x, int tiles_y, int &tx, int &ty)
 {
     constexpr unsigned CB = 64u;
     const unsigned total = (unsigned)tiles_x * tiles_y;
-    const unsigned xcd = b & 7u, q = b >> 3;
-    // ids 0..total-1 dealt round-robin: XCD k owns ceil((total - k) / 8) of them
-    const unsigned base = total >> 3, rem = total & 7u;
-    const unsigned v = xcd * base + min(xcd, rem) + q;  // position in the column-block order
+    const unsigned xcd = b & 7u, q = b >> 3;                          // the q-th workgroup of this XCD
+    const unsigned v = ((q / SHADE_RUN) * 8u + xcd) * SHADE_RUN + q % SHADE_RUN;  // position in the column-block order
+    if (v >= total) return false;
     const unsigned block_tiles = CB * (unsigned)tiles_y;
     const unsigned cb = min(v / block_tiles, (unsigned)(tiles_x - 1) / CB);
     const unsigned r = v - cb * block_tiles;
     const unsigned cbw = min(CB, (unsigned)tiles_x - cb * CB);
     ty = (int)(r / cbw);
     tx = (int)(cb * CB + r % cbw);
+    return true;
 }
 
 // Five waves per SIMD (96 VGPRs, none spilled).  Measured at 4K / 64 lights with this loop: 5 waves 3.58 ms,
@@ -390,7 +401,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     // one wave per workgroup, one 8x8-pixel tile per wave
     const int lane = threadIdx.x;
     int tile_x, tile_y;
-    tile_of_block(blockIdx.x, p.tiles_x, p.tiles_y, tile_x, tile_y);
+    if (!tile_of_block(blockIdx.x, p.tiles_x, p.tiles_y, tile_x, tile_y)) return;
     const int x = tile_x * 8 + (lane & 7);
     const int y = tile_y * 8 + (lane >> 3);
     if (x >= p.width || y >= p.rows) return;
@@ -420,9 +431,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     const bool degenerate_normal = !(dot3(nraw, nraw) > 0.0f);
 
     float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
-    if (p.background) { rgba bg = unpack4(p.background[px]); c0 = bg.r; c1 = bg.g; c2 = bg.b; }
+    const bool resume = p.light_begin > 0;  // launch-uniform
+    if (resume) {
+        // The targets as the launch for the lights before light_begin left them: binary16 values, so reading them
+        // back is exact and the chain of per-draw roundings goes on as if it had never been cut.
+        const rgba pc = unpack4(p.out_color[px]), pt = unpack4(p.out_threshold[px]);
+        c0 = pc.r; c1 = pc.g; c2 = pc.b; t0 = pt.r; t1 = pt.g; t2 = pt.b;
+    } else if (p.background) { rgba bg = unpack4(p.background[px]); c0 = bg.r; c1 = bg.g; c2 = bg.b; }
 
-    if (al.a != 0.0f) {  // composition.frag:39-43
+    if (!resume && al.a != 0.0f) {  // composition.frag:39-43
         f3 Lo;
         {
             f3 L = normalize3(neg3(mk3(p.dir_dir[0], p.dir_dir[1], p.dir_dir[2])));
@@ -476,9 +493,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         typedef const __attribute__((address_space(4))) float cfloat;
         cfloat *lights_c = (cfloat *)p.lights;
         f3 lp_next = mk3(0.0f, 0.0f, 0.0f), lc_next = lp_next;
-        if (p.n_lights > 0) {
-            lp_next = mk3(lights_c[16], lights_c[17], lights_c[18]);
-            lc_next = mk3(lights_c[20], lights_c[21], lights_c[22]);
+        if (p.light_end > p.light_begin) {
+            cfloat *lf = lights_c + p.light_begin * 23;
+            lp_next = mk3(lf[16], lf[17], lf[18]);
+            lc_next = mk3(lf[20], lf[21], lf[22]);
         }
         typedef const __attribute__((address_space(4))) unsigned long long cmask;
         cmask *cover_c = (cmask *)p.coverage;
@@ -490,10 +508,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         // in the instruction cache.
         auto light_loop = [&](auto use_masks) {
         constexpr bool MASKS = decltype(use_masks)::value;
-        for (int li = 0; li < p.n_lights; li++) {
+        for (int li = p.light_begin; li < p.light_end; li++) {
             const f3 lp = lp_next, lc = lc_next;
             {
-                cfloat *lf = lights_c + min(li + 1, p.n_lights - 1) * 23;
+                cfloat *lf = lights_c + min(li + 1, p.light_end - 1) * 23;
                 lp_next = mk3(lf[16], lf[17], lf[18]);
                 lc_next = mk3(lf[20], lf[21], lf[22]);
             }
@@ -676,7 +694,8 @@ extern "C" int32_t vkr_shade(const VkrShadeArgs *a, void *stream)
 
     p.tiles_x = (a->width + 7) / 8; p.tiles_y = (a->rows + 7) / 8;
     VKR_REQUIRE((int64_t)p.tiles_x * p.tiles_y < (1ll << 31), "vkr_shade: strip too large");
-    const dim3 grid((unsigned)(p.tiles_x * p.tiles_y));
+    const unsigned round_tiles = 8u * SHADE_RUN;  // whole rounds of one run per XCD (see tile_of_block)
+    const dim3 grid(((unsigned)(p.tiles_x * p.tiles_y) + round_tiles - 1) / round_tiles * round_tiles);
     const bool pow2 = a->n_lights > 0 && (a->cube_res & (a->cube_res - 1)) == 0;
     const bool masked = p.coverage != nullptr;
     typedef void (*kernel_t)(const ShadeParams);
@@ -685,6 +704,17 @@ extern "C" int32_t vkr_shade(const VkrShadeArgs *a, void *stream)
         shade_kernel<1, false, false>, shade_kernel<1, false, true>, shade_kernel<1, true, false>, shade_kernel<1, true, true>,
         shade_kernel<2, false, false>, shade_kernel<2, false, true>, shade_kernel<2, true, false>, shade_kernel<2, true, true>};
     const kernel_t kernel = kernels[a->cube_layout * 4 + (pow2 ? 2 : 0) + (masked ? 1 : 0)];
-    hipLaunchKernelGGL(kernel, grid, dim3(64), 0, as_stream(stream), p);
+    // Many lights are drawn in several launches of `chunk` lights each: the waves of a launch drift apart as they
+    // skip different lights, and with them the shadow cubes the resident waves of an XCD read from drift apart too,
+    // until that XCD's L2 no longer holds them.  A cut costs a re-read of the G-buffer and the targets (48 bytes per
+    // pixel) and changes no bit: between two draws the targets are binary16 values, in registers or in memory.
+    static const int forced_chunk = getenv("VKR_SHADE_CHUNK") ? atoi(getenv("VKR_SHADE_CHUNK")) : -1;  // experiments; 0: one launch
+    const int chunk = forced_chunk > 0 ? forced_chunk : (forced_chunk == 0 ? a->n_lights : SHADE_LIGHTS_PER_LAUNCH);
+    p.light_begin = 0;
+    do {
+        p.light_end = a->n_lights - p.light_begin <= chunk + chunk / 2 ? a->n_lights : p.light_begin + chunk;  // no short tail launch
+        hipLaunchKernelGGL(kernel, grid, dim3(64), 0, as_stream(stream), p);
+        p.light_begin = p.light_end;
+    } while (p.light_begin < a->n_lights);
     return launch_status("vkr_shade");
 }
