@@ -370,6 +370,21 @@ def time_ibl(device, reps: int = 3) -> tuple[dict, list]:
              gather={"bytes": gather_bytes, "GB/s": round(gather_bytes / (irr_ms * 1e-3) / 1e9, 1),
                      "note": "32 B of texels per bilinear sample, served by L1/L2/Infinity Cache; the memory-side line traffic is in profiles/"}),
     ]
+    # The irradiance kernel is bound by the rate at which the path behind a missing L2 delivers cache lines (every
+    # bilinear tap lands on a different line of a 201 MB cube), not by its arithmetic: set its L2-miss line traffic
+    # (committed counter passes of the same kernel and sizes) beside the rate a pure random-line read reaches.
+    try:
+        with open(os.path.join(ROOT, COUNTER_FILE)) as fh:
+            crec = json.load(fh)
+        lines = crec["ibl"]["kernels"]["irradiance_texel_kernel"]["l2_miss_line_bytes"]
+        ceiling = crec["random_line_read_GBps"]["by_table_size"]["256 MiB"]
+        rate = lines / (irr_ms * 1e-3) / 1e9
+        roof[-1]["line_traffic"] = {"bound": "l2-miss line reads", "bytes": lines, "achieved": round(rate, 1), "peak": ceiling, "unit": "GB/s",
+                                    "frac": round(rate / ceiling, 4), "algorithmic_bytes": gather_bytes,
+                                    "source": f"{COUNTER_FILE}: TCC_MISS_sum x 128 B of one launch (scratch/pmc_ibl2.sh); peak = random 128-byte lines from a 256 MiB table "
+                                              "(scratch/ubench/gather_bench, profiles/r2_gather_bench.txt); neither is read in this run"}
+    except (OSError, KeyError):
+        pass
     for m in range(5):
         n = 128 >> m
         roof.append(valu(f"prefilter_texel_kernel mip {m} (roughness {m / 4:g})", OPS_PREFILTER_SAMPLE * GGX_SAMPLES * 6 * n * n, pre_ms[m],

@@ -1,6 +1,8 @@
 """Turns the CSVs of scratch/pmc_frame.sh (rocprofv3 --pmc passes over `bench.py --steps 3 --warmup 1 --no-ibl
 --no-coverage --cpu-rows 0`) into profiles/r2_counters.json, the per-launch counter figures bench.py puts beside
-its timings.  usage: python scratch/pmc_to_json.py gpurun_out/<dir> profiles/r2_counters.json"""
+its timings.  usage: python scratch/pmc_to_json.py gpurun_out/<dir> profiles/r2_counters.json [gpurun_out/<ibl dir> gather_bench.txt]
+The optional pair adds the L2-miss line traffic of the irradiance and prefilter kernels (scratch/pmc_ibl2.sh) and the
+random-line read rates of scratch/ubench/gather_bench."""
 import collections, csv, glob, json, sys
 
 root, out = sys.argv[1], sys.argv[2]
@@ -37,6 +39,28 @@ for k, ctr in acc.items():
         e["wave_lights_without_taps_frac"] = round(1.0 - taps / (waves * L), 4)
         e["wave_lights_without_taps_note"] = "1 - (SQ_INSTS_VMEM_RD - 25 x waves) / (20 x waves x lights): pairs skipped because the wave faces away from the light or is cleared background"
     rec["kernels"][k] = e
+if len(sys.argv) > 4:
+    import re
+    ibl = {"irradiance_texel_kernel": collections.defaultdict(list), "prefilter_texel_kernel": collections.defaultdict(list)}
+    for path in glob.glob(sys.argv[3] + "/**/*counter_collection.csv", recursive=True):
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                for k in ibl:
+                    if k in row["Kernel_Name"]:
+                        ibl[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    rec["ibl"] = {"command": "rocprofv3 --pmc <counters> -- python3 scratch/ibl_one.py (one launch of each IBL kernel at the 2048^2 configuration)", "kernels": {}}
+    for k, ctr in ibl.items():
+        per_run = 5 if k.startswith("prefilter") else 1  # prefilter: the sum over its five mips
+        tot = {n: sum(v) / len(v) * per_run for n, v in ctr.items()}
+        rec["ibl"]["kernels"][k] = {"launches_per_run": per_run, "TCC_MISS_sum": int(tot["TCC_MISS_sum"]), "TCC_HIT_sum": int(tot["TCC_HIT_sum"]),
+                                    "l2_miss_line_bytes": int(tot["TCC_MISS_sum"]) * 128, "fetch_bytes": int(tot["FETCH_SIZE"] * 2 * 1024)}
+    rates = {}
+    for line in open(sys.argv[4]):
+        m = re.match(r"random lines, (\S+ \S+) table\s+m0\s+[\d.]+ cyc \(([\d.]+) TB/s", line)
+        if m:
+            rates[m.group(1)] = float(m.group(2)) * 1000.0
+    rec["random_line_read_GBps"] = {"by_table_size": rates, "source": "scratch/ubench/gather_bench: every lane of every gather reads its own random 128-byte line "
+                                    "(32 waves per CU); what the path behind a missing L2 delivers, whatever the kernel"}
 with open(out, "w") as fh:
     json.dump(rec, fh, indent=1)
 print(json.dumps(rec["kernels"], indent=1))
