@@ -237,7 +237,7 @@ def phase_times(renderer, dev_frame, world: int, steps: int, device) -> dict:
     not hide; gather is the RGBA8 transfer to rank 0 (on the side stream: it overlaps the next frame)."""
     import torch
     import torch.distributed as dist
-    names = ["edge_bands_shade", "interior_shade", "interior_bloom_post", "halo_wait", "edge_bloom_post", "gather"]
+    names = ["shade", "interior_bloom_post", "halo_wait", "edge_bloom_post", "gather"]
     acc = {n: 0.0 for n in names}
     for _ in range(steps):
         renderer.marks = []
@@ -246,7 +246,7 @@ def phase_times(renderer, dev_frame, world: int, steps: int, device) -> dict:
             renderer.gather(0)
         torch.cuda.synchronize()
         ev = dict(renderer.marks)
-        order = ["frame_start"] + names[:5]
+        order = ["frame_start"] + names[:4]
         for a, b in zip(order, order[1:]):
             acc[b] += ev[a].elapsed_time(ev[b])
         if "gather" in ev:

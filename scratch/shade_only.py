@@ -10,6 +10,7 @@ import bench
 from vulkanrenderer_amd import passes as P, synth
 dev = torch.device("cuda", 0)
 L = int(os.environ.get("VKR_LIGHTS", "64"))
+bench.HEIGHT = int(os.environ.get("VKR_HEIGHT", bench.HEIGHT))  # e.g. 270: the strip of an 8-way split
 scene = bench.build_scene(dev, L, bench.CUBE_RES, bench.DIR_RES)
 if os.environ.get("VKR_C5"):
     # the per-GPU share of the 16384^2 / 256-light configuration, built as bench.py builds it: a 4096-wide synthetic

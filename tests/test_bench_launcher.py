@@ -58,5 +58,5 @@ def test_self_launched_ranks_render_one_frame_in_strips(gpu):
     assert line["n_gpus"] == 2 and line["scaling"] == "strong"
     assert line["distributed"]["backend"] == "gloo" and line["distributed"]["world"] == 2
     assert line["gathered_equals_single_gpu"] is True
-    assert line["value"] > 0 and set(line["phases_ms"]) >= {"halo_wait", "gather", "interior_shade", "interior_bloom_post"}
+    assert line["value"] > 0 and set(line["phases_ms"]) >= {"halo_wait", "gather", "shade", "interior_bloom_post"}
     assert "48 rows" in line["config"]["workload"]

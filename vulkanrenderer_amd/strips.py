@@ -162,11 +162,15 @@ class StripRenderer:
             self.marks.append((name, ev))
 
     def render(self, frame, volume_mesh=None) -> torch.Tensor:
-        """composition of the rows next to a neighbour -> halo exchange of their thresholded rows, overlapped
-        with the composition of all other rows and the bloom + post-process kernel over the rows that reach no
-        halo row -> the rows next to a neighbour; returns the RGBA8 strip.  With `volume_mesh`
-        each light's draw is limited to the pixels its volume covers; the strip's place in the
-        frame (plan.row0 of plan.total_rows) enters the projection, nothing is exchanged for it."""
+        """composition of the strip -> halo exchange of its boundary thresholded rows, overlapped with the bloom +
+        post-process kernel over the rows that reach no halo row -> the rows next to a neighbour; returns the
+        RGBA8 strip.  With `volume_mesh` each light's draw is limited to the pixels its volume covers; the strip's
+        place in the frame (plan.row0 of plan.total_rows) enters the projection, nothing is exchanged for it.
+
+        The strip is shaded in ONE launch: a launch of the shading kernel costs about 4 us per light before its
+        first wave retires and after its last one starts (every wave walks all lights in order), whatever its
+        size, so shading the boundary rows in launches of their own to start the exchange earlier costs far more
+        (0.27 ms per launch at 64 lights) than the exchange (tens of microseconds) it would hide."""
         p, r = self.plan, self.plan.rows
         be = self.backend
         self.ldr = self._ring[self._slot]
@@ -181,19 +185,10 @@ class StripRenderer:
         # rows [top, bottom) reach no halo row: they run while the halo rows are in flight
         top = 0 if p.is_top else HALO
         bottom = r if p.is_bottom else r - HALO
-        # The rows a neighbour needs are shaded first (bands of whole 8-row tiles), so that the halo exchange is
-        # in flight during the shading of everything else, the long part of a frame.
-        a = 0 if p.is_top else min(8, r)
-        b = r if p.is_bottom else max(((r - HALO) // 8) * 8, a)
         self._mark("frame_start")
-        for y0, y1 in ((0, a), (b, r)):
-            if y1 > y0:
-                be.shade(frame, self.color, self.threshold, y0, y1)
-        self._mark("edge_bands_shade")
+        be.shade(frame, self.color, self.threshold)
+        self._mark("shade")
         pending = self.start_halo_exchange()
-        if b > a:
-            be.shade(frame, self.color, self.threshold, a, b)
-        self._mark("interior_shade")
         if bottom > top:
             be.bloom_post(self.threshold_padded, self.color[top:bottom], self.ldr[top:bottom], lo, hi, row0=top)
         self._mark("interior_bloom_post")
