@@ -637,8 +637,9 @@ def main() -> None:
     plan = StripPlan.make(rank, world, HEIGHT)
     f = whole.rows(plan.row0, plan.row0 + plan.rows)
     dev_frame = P.DeviceFrame.upload(f, device)  # scene data + this rank's rows; cubes re-laid into tiles once
-    # two frames in flight, like the reference (VulkanRenderer.cs:60): the gather of frame k overlaps frame k+1
-    renderer = StripRenderer(plan, WIDTH, device=device, frames_in_flight=2 if world > 1 else 1)
+    # two frames in flight, like the reference (VulkanRenderer.cs:60), each on a stream of its own: the last waves and
+    # the gather of frame k overlap the first waves of frame k+1
+    renderer = StripRenderer(plan, WIDTH, device=device, frames_in_flight=2)
 
     elapsed = timed_frames(renderer, dev_frame, world, args.steps, args.warmup, device)
     phases = phase_times(renderer, dev_frame, world, args.steps, device)

@@ -107,9 +107,9 @@ def _pipelined_worker(rank, world, port, out_path):
         dev = torch.device("cuda", 0)
         plan = StripPlan.make(rank, world, H)
         r = StripRenderer(plan, W, device=dev, frames_in_flight=2)
-        assert r._side is not None
+        assert all(slot["stream"] is not None for slot in r._slots)
         held = []
-        for seed in (91, 92, 93, 94):  # four frames through two output strips, gathers on the side stream
+        for seed in (91, 92, 93, 94):  # four frames through two output strips, each frame on the stream of its set of targets
             f = synth.make_frame(seed, W, H, LIGHTS, 32, 128, irr_res=8, pref_res=16, lut_res=32)
             r.render(P.DeviceFrame.upload(f.rows(plan.row0, plan.row0 + plan.rows), dev))
             parts = r.gather(0)

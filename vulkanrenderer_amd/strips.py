@@ -109,23 +109,39 @@ class StripRenderer:
     """Runs the per-frame chain on this rank's strip.  `backend` defaults to the HIP kernels."""
 
     def __init__(self, plan: StripPlan, width: int, device=None, backend=None, group=None, frames_in_flight: int = 1):
-        """`frames_in_flight` > 1 (the reference keeps 2, VulkanRenderer.cs:60): that many RGBA8 output
-        strips, so that gather() of one frame can run on a side stream while the next frame is shaded."""
+        """`frames_in_flight` > 1 (the reference keeps 2, VulkanRenderer.cs:60): that many sets of targets, each with a
+        HIP stream of its own.  Consecutive frames then overlap on the GPU: while the last waves of frame k walk
+        their lights and its RGBA8 strip travels to rank 0, the first waves of frame k+1 are already running.
+        With one frame in flight everything runs on the caller's current stream."""
         self.plan, self.width, self.group = plan, width, group
         self.backend = backend if backend is not None else HipBackend(device)
         r = plan.rows
-        self.color = self.backend.empty((r, width, 4), torch.float16)
-        # the thresholded image with HALO rows of each neighbour above and below the strip's own rows
-        self.threshold_padded = self.backend.empty((r + 2 * HALO, width, 4), torch.float16)
-        self.threshold = self.threshold_padded[HALO:HALO + r]
-        self._ring = [self.backend.empty((r, width, 4), torch.uint8) for _ in range(max(frames_in_flight, 1))]
+        self._slots = []
+        for _ in range(max(frames_in_flight, 1)):
+            # the thresholded image carries HALO rows of each neighbour above and below the strip's own rows
+            padded = self.backend.empty((r + 2 * HALO, width, 4), torch.float16)
+            self._slots.append(dict(color=self.backend.empty((r, width, 4), torch.float16), threshold_padded=padded,
+                                    threshold=padded[HALO:HALO + r], ldr=self.backend.empty((r, width, 4), torch.uint8),
+                                    stream=None, gathered=None))
+        if self._slots[0]["ldr"].is_cuda and len(self._slots) > 1:
+            for slot in self._slots:
+                slot["stream"] = torch.cuda.Stream(device=slot["ldr"].device)
         self._slot = 0
-        self.ldr = self._ring[0]
-        on_gpu = self.ldr.is_cuda
-        self._side = torch.cuda.Stream(device=self.ldr.device) if on_gpu and len(self._ring) > 1 and plan.world > 1 else None
-        self._slot_free = [None] * len(self._ring)  # per output strip: event "its last gather has finished"
-        self._gathered = [None] * len(self._ring)   # per output strip: rank dst's receive buffers, allocated on first use
+        self._use(self._slots[0])
         self.marks = None  # a list: render() and gather() append (phase name, event recorded when the phase's work ends)
+
+    def _use(self, slot) -> None:
+        # the targets of the frame being rendered (or rendered last)
+        self.color, self.threshold, self.threshold_padded, self.ldr = slot["color"], slot["threshold"], slot["threshold_padded"], slot["ldr"]
+
+    def _on_slot_stream(self, slot):
+        """Context in which the work of `slot`'s frame is enqueued: its own stream, ordered after what the caller's
+        current stream holds so far (the frame's inputs), or the caller's stream when there is one frame in flight."""
+        import contextlib
+        if slot["stream"] is None:
+            return contextlib.nullcontext()
+        slot["stream"].wait_stream(torch.cuda.current_stream())
+        return torch.cuda.stream(slot["stream"])
 
     def start_halo_exchange(self) -> list:
         """The first HALO rows of the strip's thresholded image go to the rank above, the last HALO to the rank
@@ -155,10 +171,10 @@ class StripRenderer:
             return self.render(self.backend.frame_from_draws(frame, draws, shadow_res, dir_res, p.total_rows, p.row0), volume_mesh)
         return self.render(self.backend.frame_from_draws(frame, draws, shadow_res, dir_res, p.total_rows, p.row0, env), volume_mesh)
 
-    def _mark(self, name: str, stream=None) -> None:
+    def _mark(self, name: str) -> None:
         if self.marks is not None and self.ldr.is_cuda:
             ev = torch.cuda.Event(enable_timing=True)
-            ev.record(stream if stream is not None else torch.cuda.current_stream())
+            ev.record(torch.cuda.current_stream())
             self.marks.append((name, ev))
 
     def render(self, frame, volume_mesh=None) -> torch.Tensor:
@@ -167,16 +183,24 @@ class StripRenderer:
         RGBA8 strip.  With `volume_mesh` each light's draw is limited to the pixels its volume covers; the strip's
         place in the frame (plan.row0 of plan.total_rows) enters the projection, nothing is exchanged for it.
 
-        The strip is shaded in ONE launch: a launch of the shading kernel costs about 4 us per light before its
-        first wave retires and after its last one starts (every wave walks all lights in order), whatever its
-        size, so shading the boundary rows in launches of their own to start the exchange earlier costs far more
-        (0.27 ms per launch at 64 lights) than the exchange (tens of microseconds) it would hide."""
+        The strip is shaded in ONE launch: every wave walks all lights in order, so a launch fills and drains the
+        machine for about one wave lifetime (4 us per light) whatever its size; launches that follow each other
+        hide most of that, but each extra one still costs 0.05-0.1 ms at 64 lights -- more than the exchange
+        (tens of microseconds) that shading the boundary rows first would hide."""
+        slot = self._slots[self._slot]
+        self._use(slot)
+        if slot["stream"] is not None:
+            # the frame's tensors were allocated on the caller's stream: tell the allocator that this stream reads them,
+            # so that dropping the frame does not hand their memory to a new allocation while the kernels still run
+            for v in vars(frame).values():
+                if isinstance(v, torch.Tensor) and v.is_cuda:
+                    v.record_stream(slot["stream"])
+        with self._on_slot_stream(slot):
+            return self._render(frame, volume_mesh)
+
+    def _render(self, frame, volume_mesh):
         p, r = self.plan, self.plan.rows
         be = self.backend
-        self.ldr = self._ring[self._slot]
-        if self._slot_free[self._slot] is not None:  # this output strip may still be on its way to rank 0
-            torch.cuda.current_stream().wait_event(self._slot_free[self._slot])
-            self._slot_free[self._slot] = None
         if volume_mesh is not None:
             frame = be.with_coverage(frame, volume_mesh, p.total_rows, p.row0)
         # frame edges clamp (CLAMP_TO_EDGE); interior strip edges read the neighbours' rows
@@ -204,38 +228,33 @@ class StripRenderer:
 
     def gather(self, dst: int = 0):
         """Collects the RGBA8 strips of the frame just rendered on rank `dst` (list of tensors there, None
-        elsewhere).  With several frames in flight on a GPU the transfer runs on a side stream and the
-        next render() goes on at once; the returned tensors are complete once that stream (or the
-        device) is synchronised, and stay untouched until as many further frames as there are frames in
-        flight have been gathered (every output strip of the ring has receive buffers of its own)."""
-        ldr = self.ldr
-        slot, self._slot = self._slot, (self._slot + 1) % len(self._ring)
+        elsewhere).  With several frames in flight the transfer is enqueued on the frame's own stream and the next
+        render() goes on at once on another; the returned tensors are complete once that stream (or the device) is
+        synchronised, and stay untouched until as many further frames as there are frames in flight have been
+        gathered (every set of targets has receive buffers of its own)."""
+        slot = self._slots[self._slot]
+        self._slot = (self._slot + 1) % len(self._slots)
         if self.plan.world == 1:
-            return [ldr]
-        if self._side is None:
+            return [slot["ldr"]]
+        with self._on_slot_stream(slot):
             self._mark("gather_start")
-            parts = self._gather_now(ldr, dst, slot)
+            parts = self._gather_now(slot, dst)
             self._mark("gather")
-            return parts
-        rendered = torch.cuda.Event()
-        rendered.record()
-        with torch.cuda.stream(self._side):
-            self._side.wait_event(rendered)
-            self._mark("gather_start", self._side)
-            parts = self._gather_now(ldr, dst, slot)
-            self._mark("gather", self._side)
-            done = torch.cuda.Event()
-            done.record(self._side)
-        self._slot_free[slot] = done
         return parts
 
-    def _gather_now(self, ldr, dst: int, slot: int = 0):
-        p = self.plan
+    def synchronize(self) -> None:
+        """Makes the caller's current stream wait for every frame in flight."""
+        for slot in self._slots:
+            if slot["stream"] is not None:
+                torch.cuda.current_stream().wait_stream(slot["stream"])
+
+    def _gather_now(self, slot, dst: int):
+        p, ldr = self.plan, slot["ldr"]
         if p.rank == dst:
-            if self._gathered[slot] is None:
-                self._gathered[slot] = [self.backend.empty((StripPlan.make(k, p.world, p.total_rows).rows, self.width, 4), torch.uint8)
-                                        for k in range(p.world)]
-            parts = list(self._gathered[slot])
+            if slot["gathered"] is None:
+                slot["gathered"] = [self.backend.empty((StripPlan.make(k, p.world, p.total_rows).rows, self.width, 4), torch.uint8)
+                                    for k in range(p.world)]
+            parts = list(slot["gathered"])
             ops = [dist.P2POp(dist.irecv, parts[k], k, self.group) for k in range(p.world) if k != dst]
             parts[dst] = ldr
             for req in dist.batch_isend_irecv(ops):
