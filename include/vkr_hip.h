@@ -72,8 +72,10 @@ typedef struct VkrLightInfo {
 /* Memory layout of the D32F point-shadow cubes (the reference keeps them in OPTIMAL-tiled Vulkan
  * images, VulkanRenderer.cs:1348-1370, whose layout is the driver's; here it is explicit). */
 #define VKR_CUBE_LAYOUT_LINEAR 0    /* [light][face][row][column], tight */
-#define VKR_CUBE_LAYOUT_TILED_8X4 1 /* each face as row-major 8x4-texel tiles of 128 bytes; face size % 8 == 0;
-                                       made from the linear layout by vkr_tile_depth_cubes() */
+#define VKR_CUBE_LAYOUT_TILED_8X4 1 /* each face as 8x4-texel tiles of 128 bytes (rows of 8 texels inside a tile), the
+                                       tiles stored column by column: texel (i, j) of a face of size n is float number
+                                       (i / 8) * 8n + 8j + i % 8 of the face; face size % 8 == 0; made from the linear
+                                       layout by vkr_tile_depth_cubes() */
 #define VKR_CUBE_LAYOUT_TILED_8X4_X25 2 /* the same tiles holding RN(25 * depth), the product light.frag:133 forms for
                                            every tap (25 = the shadow passes' far plane, VulkanRenderer.cs:331): the
                                            shading kernel then compares without multiplying; made by

@@ -490,7 +490,7 @@ def test_tiled_cube_layout(gpu, oracle):
     got = P.tile_depth_cubes(lin).cpu().numpy().reshape(12, -1)
     src = lin.cpu().numpy().reshape(12, res, res)
     j, i = np.meshgrid(np.arange(res), np.arange(res), indexing="ij")
-    index = ((j >> 2) * (res >> 3) + (i >> 3)) * 32 + (j & 3) * 8 + (i & 7)
+    index = (i >> 3) * (res * 8) + j * 8 + (i & 7)  # 8x4-texel tiles, stored column by column
     want = np.empty_like(got)
     want[:, index.ravel()] = src.reshape(12, -1)
     assert np.array_equal(got, want)
@@ -766,7 +766,7 @@ def test_point_shadow_maps_bit_exact(gpu, oracle, res, tiled):
     got = got.cpu().numpy()
     if tiled is not False:
         j, i = np.meshgrid(np.arange(res), np.arange(res), indexing="ij")
-        index = ((j >> 2) * (res >> 3) + (i >> 3)) * 32 + (j & 3) * 8 + (i & 7)
+        index = (i >> 3) * (res * 8) + j * 8 + (i & 7)  # 8x4-texel tiles, stored column by column
         got = got.reshape(len(lights), 6, -1)[:, :, index.ravel()].reshape(want.shape)
     if tiled is None:
         assert layout == _lib.CUBE_LAYOUT_TILED_8X4_X25

@@ -52,7 +52,7 @@ VKR_DEV void shadow_face_matrix_elem(const float *eye, int face, float far_plane
 VKR_DEV size_t depth_texel_index(int res, int i, int j, bool tiled)
 {
     if (!tiled) return (size_t)j * res + i;
-    return (size_t)(((unsigned)j >> 2) * ((unsigned)res >> 3) + ((unsigned)i >> 3)) * 32u + ((unsigned)j & 3u) * 8u + ((unsigned)i & 7u);
+    return (size_t)((unsigned)i >> 3) * ((unsigned)res * 8u) + (unsigned)j * 8u + ((unsigned)i & 7u);  // tiles column by column
 }
 
 // The triangles of the wave's lanes into one res x res depth image each (`img` may differ per lane only
