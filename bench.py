@@ -527,7 +527,7 @@ def cpu_baseline(f, gpu_color, gpu_thr, sample_rows: int) -> dict:
             "gpu_rows_bit_exact": exact}
 
 
-def extra_shapes(args, rank: int, world: int, device, scene: dict, scene_dev) -> dict:
+def extra_shapes(args, rank: int, world: int, device, scene: dict, scene_dev, weak: bool = True) -> dict:
     """The two other N > 1 shapes: a full-size strip per rank (weak scaling) and the per-GPU share of the
     16384^2 / 256-light frame.  Inputs are synthetic repeats: timing only, the parity of these shapes is the
     test suite's business."""
@@ -539,16 +539,17 @@ def extra_shapes(args, rank: int, world: int, device, scene: dict, scene_dev) ->
     steps, warmup = max(args.steps // 2, 3), 2
 
     # (a) weak: every rank owns a WIDTH x HEIGHT strip of a WIDTH x (HEIGHT * world) frame
-    g = synth.make_gbuffer(np.random.default_rng(SEED + 1000 + rank), WIDTH, HEIGHT)
-    f = frame_of(scene, g, WIDTH, HEIGHT)
-    dev_frame = strip_device_frame(scene_dev, f, 0, HEIGHT, device)
-    r = StripRenderer(StripPlan.make(rank, world, HEIGHT * world), WIDTH, device=device, frames_in_flight=2)
-    t = timed_frames(r, dev_frame, world, steps, warmup, device)
-    out["weak_full_strip_per_rank"] = {"frame": f"{WIDTH}x{HEIGHT * world}", "strip": f"{WIDTH}x{HEIGHT}", "lights": args.lights, "scaling": "weak",
-                                       "ms_per_step": round(t / steps * 1e3, 4), "Mpixels/s": round(WIDTH * HEIGHT * world / (t / steps) / 1e6, 1),
-                                       "phases_ms": phase_times(r, dev_frame, world, steps, device)}
-    del r, dev_frame, f, g
-    torch.cuda.empty_cache()
+    if weak:
+      g = synth.make_gbuffer(np.random.default_rng(SEED + 1000 + rank), WIDTH, HEIGHT)
+      f = frame_of(scene, g, WIDTH, HEIGHT)
+      dev_frame = strip_device_frame(scene_dev, f, 0, HEIGHT, device)
+      r = StripRenderer(StripPlan.make(rank, world, HEIGHT * world), WIDTH, device=device, frames_in_flight=2)
+      t = timed_frames(r, dev_frame, world, steps, warmup, device)
+      out["weak_full_strip_per_rank"] = {"frame": f"{WIDTH}x{HEIGHT * world}", "strip": f"{WIDTH}x{HEIGHT}", "lights": args.lights, "scaling": "weak",
+                                         "ms_per_step": round(t / steps * 1e3, 4), "Mpixels/s": round(WIDTH * HEIGHT * world / (t / steps) / 1e6, 1),
+                                         "phases_ms": phase_times(r, dev_frame, world, steps, device)}
+      del r, dev_frame, f, g
+      torch.cuda.empty_cache()
 
     # (b) the 16384^2 / 256-light configuration: 16384 x 2048 rows per rank, 256 lights with 1024^2 cubes
     reps = C5_LIGHTS // args.lights
@@ -588,7 +589,7 @@ def main() -> None:
     ap.add_argument("--cpu-rows", type=int, default=None, help="rows of the frame the CPU baseline shades (default: all; 0 = skip)")
     ap.add_argument("--no-ibl", action="store_true", help="skip the IBL precompute timing")
     ap.add_argument("--no-coverage", action="store_true", help="skip the light-volume coverage and shadow-pass timings")
-    ap.add_argument("--no-extra", action="store_true", help="N > 1: skip the weak-scaling and 16384-wide extra shapes")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra shapes (the 16384-wide / 256-light strip; N > 1: also a full strip per rank)")
     ap.add_argument("--transport-only", action="store_true", help="rehearse launcher, halo exchange and gather on CPU tensors (no GPU, no kernels)")
     ap.add_argument("--launch-timeout", type=float, default=900.0, help="seconds the self-started ranks may take")
     args = ap.parse_args()
@@ -663,9 +664,11 @@ def main() -> None:
         torch.cuda.synchronize()
 
     extra = {}
-    if world > 1 and not args.no_extra:
-        extra = extra_shapes(args, rank, world, device, scene, dev_frame)
-        dist.barrier()
+    if not args.no_extra:
+        # N > 1: a full strip per rank (weak scaling) and the 16384-wide / 256-light strip per rank; N = 1: the latter alone
+        extra = extra_shapes(args, rank, world, device, scene, dev_frame, weak=world > 1)
+        if world > 1:
+            dist.barrier()
 
     if rank != 0:
         if world > 1:
@@ -728,7 +731,7 @@ def main() -> None:
     }
     if world > 1:
         out["gathered_equals_single_gpu"] = gathered_ok
-        out.update(extra)
+    out.update(extra)
     if world == 1 and dev_frame.cube_layout != 0:
         rt = time_shadow_retile(f, device)
         rt["note"] = ("not part of a step: the shadow cubes are inputs resident in the tiled layout; "
