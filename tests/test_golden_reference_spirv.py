@@ -24,8 +24,11 @@ def close(got, want, ulps=2.0):
     return np.abs(got - want) <= np.maximum(1e-3, ulps * f16_ulp(want))
 
 
-def test_composition_and_light_shaders(oracle):
-    g = np.load(os.path.join(GOLDEN, "frame_composition_lights.npz"))
+@pytest.mark.parametrize("fixture", ["frame_composition_lights.npz", "frame_composition_lights_48x32.npz"])
+def test_composition_and_light_shaders(oracle, fixture):
+    """16 x 12 pixels, 2 lights, 8^2 cubes; and 48 x 32 pixels, 6 lights inside the scene's extent (every cube face and
+    face edges are selected), 16^2 cubes, 32^2 directional map."""
+    g = np.load(os.path.join(GOLDEN, fixture))
     h, w = g["albedo"].shape[:2]
     f = synth.FrameInputs(w, h, g["albedo"], g["normal"], g["arm"], g["position"], g["scene"][()], g["lights"],
                           g["dir_shadow"], g["cube_shadow"], g["irradiance"], g["prefilter"], g["brdf_lut"])

@@ -47,20 +47,16 @@ def blocky(rng, shape, block, values):
     return np.ascontiguousarray(small[tuple(slice(0, s) for s in shape)].astype(np.float32))
 
 
-def main(spv_dir):
-    os.makedirs(OUT, exist_ok=True)
-    t0 = time.time()
-
-    # ---- frame: composition.frag + light.frag -----------------------------------------------------
-    W, H, NL = 16, 12, 2
-    f = synth.make_frame(1234, W, H, NL, 8, 16, irr_res=4, pref_res=4, lut_res=8)
-    rng = np.random.default_rng(99)
-    f.dir_shadow = blocky(rng, (16, 16), 4, [0.05, 0.95])
-    f.cube_shadow = np.stack([blocky(rng, (6, 8, 8), 4, [0.02, 0.9]) for _ in range(NL)])
+def frame_vectors(spv_dir, name, rng, W, H, cube_res, dir_res, seed, light_pos, light_col, cleared, t0):
+    """composition.frag and one light.frag draw per light over a W x H frame, blended into binary16 targets."""
+    NL = len(light_pos)
+    f = synth.make_frame(seed, W, H, NL, cube_res, dir_res, irr_res=4, pref_res=4, lut_res=8)
+    f.dir_shadow = blocky(rng, (dir_res, dir_res), 4, [0.05, 0.95])
+    f.cube_shadow = np.stack([blocky(rng, (6, cube_res, cube_res), 4, [0.02, 0.9]) for _ in range(NL)])
     for img in (f.albedo, f.normal, f.arm, f.position):   # a cleared block: the composition draw discards there
-        img[4:8, 8:12] = 0
-    f.lights["position"] = [(0.8, 1.7, -0.6), (-1.4, 2.3, 1.1)]
-    f.lights["color"] = [(30.0, 25.0, 20.0), (9.0, 21.0, 24.0)]
+        img[cleared] = 0
+    f.lights["position"] = light_pos
+    f.lights["color"] = light_col
     gb = {k: Tex2D(h2f(getattr(f, k)), "linear", "repeat") for k in ("albedo", "normal", "arm", "position")}
     scene = f.scene
     lsm = np.asarray(scene["light_space_matrix"], dtype=np.float32).reshape(4, 4)  # row i = GLSL column i
@@ -97,11 +93,30 @@ def main(spv_dir):
                 thr[y, x] = f16r(thr[y, x] + rl["out"][1][:3])
     lum = lambda c: c[..., 0] * 0.2126 + c[..., 1] * 0.7152 + c[..., 2] * 0.0722
     near_threshold = (np.abs(lum(comp_raw) - 1.0) < 2e-3) | (np.abs(lum(light_raw) - 1.0) < 2e-3).any(axis=0)
-    np.savez_compressed(os.path.join(OUT, "frame_composition_lights.npz"),
+    np.savez_compressed(os.path.join(OUT, name),
                         albedo=f.albedo, normal=f.normal, arm=f.arm, position=f.position, scene=scene, lights=f.lights,
                         dir_shadow=f.dir_shadow, cube_shadow=f.cube_shadow, irradiance=f.irradiance, prefilter=f.prefilter,
                         brdf_lut=f.brdf_lut, color=color, threshold=thr, killed=killed, near_threshold=near_threshold)
-    print("frame", time.time() - t0, "s; ops", comp.ops + light.ops, "killed", killed.sum(), "near thr", near_threshold.sum())
+    print(name, time.time() - t0, "s; ops", comp.ops + light.ops, "killed", killed.sum(), "near thr", near_threshold.sum())
+
+
+def frame_vectors_large(spv_dir):
+    """A 48 x 32 frame with six lights and 16^2 cubes: lights inside the scene's extent, so the fragment-to-light
+    vectors of one frame select every cube face and cross face edges."""
+    frame_vectors(spv_dir, "frame_composition_lights_48x32.npz", np.random.default_rng(4242), 48, 32, 16, 32, 4321,
+                  [(0.8, 1.7, -0.6), (-1.4, 2.3, 1.1), (0.1, 0.6, 0.2), (2.2, 0.9, -2.0), (-2.5, 1.2, -1.5), (0.4, 2.8, 2.4)],
+                  [(30.0, 25.0, 20.0), (9.0, 21.0, 24.0), (6.0, 3.0, 2.0), (12.0, 12.0, 4.0), (2.0, 9.0, 5.0), (18.0, 6.0, 22.0)],
+                  (slice(10, 18), slice(30, 40)), time.time())
+
+
+def main(spv_dir):
+    os.makedirs(OUT, exist_ok=True)
+    t0 = time.time()
+
+    # ---- frame: composition.frag + light.frag -----------------------------------------------------
+    rng = np.random.default_rng(99)
+    frame_vectors(spv_dir, "frame_composition_lights.npz", rng, 16, 12, 8, 16, 1234,
+                  [(0.8, 1.7, -0.6), (-1.4, 2.3, 1.1)], [(30.0, 25.0, 20.0), (9.0, 21.0, 24.0)], (slice(4, 8), slice(8, 12)), t0)
 
     # ---- bloom_blur.frag: pass 1 (horizontal, textureSampler) then pass 2 (vertical, bloomSampler) --
     bw, bh = 24, 10
@@ -353,7 +368,9 @@ def shadow_vectors(spv_dir):
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     spv = args[0] if args else "/root/reference/compiled_shaders"
-    if "--only-light-vert" in sys.argv:
+    if "--only-large-frame" in sys.argv:
+        frame_vectors_large(spv)
+    elif "--only-light-vert" in sys.argv:
         light_vert_vectors(spv)
     elif "--only-gpass" in sys.argv:
         gpass_vectors(spv)
@@ -363,6 +380,7 @@ if __name__ == "__main__":
         shadow_vectors(spv)
     else:
         main(spv)
+        frame_vectors_large(spv)
         light_vert_vectors(spv)
         gpass_vectors(spv)
         skybox_vectors(spv)

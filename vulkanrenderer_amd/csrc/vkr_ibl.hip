@@ -239,13 +239,18 @@ VKR_DEV float2 ggx_theta(int s, float rough)
 // samples (environment colour and N.L) into LDS; four lanes -- red, green, blue and the weight
 // total -- then add them up in sample order, which is the shader's single running sum.
 template <bool TILED>
-__global__ __launch_bounds__(256) void prefilter_texel_kernel(const void *env, int env_n, uint2 *out, int n, float rough, int row_begin)
+__global__ __launch_bounds__(256) void prefilter_texel_kernel(const void *env, int env_n, uint2 *out, int n, float rough, int row_begin, int n_texels, int per_xcd)
 {
     __shared__ __align__(16) float term[4][SAMPLE_COUNT];  // [0..2] environment colour, [3] N.L
     __shared__ float result[4];
     const int tid = threadIdx.x;
-    const int i = blockIdx.x;
-    const int row = row_begin + blockIdx.y;
+    // Workgroups go to the 8 XCDs round-robin by id.  XCD x takes the texels [x * per_xcd, (x + 1) * per_xcd) in row-major
+    // order, so the workgroups resident on an XCD at any time are neighbours on the cube, their lobes overlap, and the
+    // XCD's L2 serves most of their lookups.
+    const int texel = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
+    if (texel >= n_texels) return;
+    const int i = texel % n;
+    const int row = row_begin + texel / n;
     const int f = row / n, j = row - f * n;
     const f3 N = normalize3(face_dir(f, i, j, n));
     const f3 tangent = __builtin_fabsf(N.z) < 0.999f ? normalize3(mk3(-N.y, N.x, 0.0f))   // cross((0,0,1), N)
@@ -440,8 +445,10 @@ extern "C" int32_t vkr_ibl_prefilter(const void *env, int32_t env_n, int32_t env
     const bool tiled = env_layout == VKR_ENV_LAYOUT_TILED_4X4;
     if ((rc = ensure_tables()) != VKR_OK) return rc;
     if (row_end == row_begin) return VKR_OK;
-    dim3 grid(n, row_end - row_begin);
-    hipLaunchKernelGGL(tiled ? prefilter_texel_kernel<true> : prefilter_texel_kernel<false>, grid, dim3(256), 0, as_stream(stream), env, env_n, (uint2 *)out, n, roughness, row_begin);
+    const int n_texels = n * (row_end - row_begin);
+    const int per_xcd = (n_texels + 7) / 8;
+    dim3 grid(8 * per_xcd);
+    hipLaunchKernelGGL(tiled ? prefilter_texel_kernel<true> : prefilter_texel_kernel<false>, grid, dim3(256), 0, as_stream(stream), env, env_n, (uint2 *)out, n, roughness, row_begin, n_texels, per_xcd);
     return launch_status("vkr_ibl_prefilter");
 }
 
