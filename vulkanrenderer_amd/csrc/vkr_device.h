@@ -193,6 +193,12 @@ VKR_DEV f3 texcube_rgb_linear(const void *cube, int n, f3 r)
 }
 
 VKR_DEV int wrap_repeat(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
+// The same for a coordinate known to be within one period of [0, n) (anything else takes the division)
+VKR_DEV int wrap_near(int i, int n)
+{
+    if (i < -n || i >= 2 * n) return wrap_repeat(i, n);
+    return i < 0 ? i + n : (i >= n ? i - n : i);
+}
 
 // Direction through the centre of texel (i,j) of face f of an n^2 cube (inverse of cube_face)
 VKR_DEV f3 face_dir(int f, int i, int j, int n)

@@ -81,14 +81,15 @@ __global__ __launch_bounds__(256) void equirect_kernel(const void *src, int sw, 
     int row = row_begin + blockIdx.y;
     if (i >= n || row >= row_end) return;
     int f = row / n, j = row - f * n;
-    f3 d = normalize3(face_dir(f, i, j, n));
+    f3 d = normalize3_fast(face_dir(f, i, j, n));
     float u = fma_(atan2f(d.z, d.x), 0.1591f, 0.5f);
     float v = 1.0f - fma_(asinf(d.y), 0.3183f, 0.5f);
     float x = u * (float)sw - 0.5f, y = v * (float)sh - 0.5f;
     float fx = __builtin_floorf(x), fy = __builtin_floorf(y);
     float al = x - fx, be = y - fy;
-    int i0 = wrap_repeat((int)fx, sw), i1 = wrap_repeat((int)fx + 1, sw);
-    int j0 = wrap_repeat((int)fy, sh), j1 = wrap_repeat((int)fy + 1, sh);
+    // u and v lie in [0, 1], so the four texel coordinates are in [-1, size]: REPEAT is one step, not a division
+    int i0 = wrap_near((int)fx, sw), i1 = wrap_near((int)fx + 1, sw);
+    int j0 = wrap_near((int)fy, sh), j1 = wrap_near((int)fy + 1, sh);
     float w00 = (1.0f - al) * (1.0f - be), w10 = al * (1.0f - be), w01 = (1.0f - al) * be, w11 = al * be;
     f3 a = fetch_src(src, fmt, sw, i0, j0), b = fetch_src(src, fmt, sw, i1, j0);
     f3 c = fetch_src(src, fmt, sw, i0, j1), e = fetch_src(src, fmt, sw, i1, j1);
