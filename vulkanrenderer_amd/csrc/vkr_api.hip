@@ -128,7 +128,7 @@ static int32_t clear_frame_sized(vkr_ctx *c)
         if (rc == VKR_OK) rc = fill_u64(f.threshold_padded, px + 2 * (size_t)c->cfg.width * VKR_STRIP_HALO_ROWS, RGBA16F_0001, c->stream);
         if (rc == VKR_OK) rc = fill_u64(f.ldr, px / 2, 0xFF000000FF000000ull, c->stream);
         if (rc != VKR_OK) return rc;
-        if (px & 1) VKR_HIP_CHECK(hipMemsetAsync((char *)f.ldr + (px - 1) * 4, 0, 4, c->stream));
+        if (px & 1) VKR_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)((char *)f.ldr + (px - 1) * 4), (int)0xFF000000u, 1, c->stream));  // (0, 0, 0, 255)
     }
     VKR_HIP_CHECK(hipStreamSynchronize(c->stream));
     return VKR_OK;
@@ -510,14 +510,18 @@ extern "C" int32_t vkr_set_light_volume_mesh(vkr_ctx *c, const float *verts, int
     VKR_REQUIRE(n_verts <= 1024, "vkr_set_light_volume_mesh: %d vertices; at most 1024 are supported", n_verts);
     for (int64_t i = 0; i < (int64_t)n_tris * 3; i++)
         VKR_REQUIRE(indices[i] < (uint32_t)n_verts, "vkr_set_light_volume_mesh: index %u at %lld is outside the %d vertices", indices[i], (long long)i, n_verts);
-    VKR_HIP_CHECK(hipStreamSynchronize(c->stream));
-    if (c->mesh_verts) { (void)hipFree(c->mesh_verts); c->mesh_verts = nullptr; }
-    if (c->mesh_indices) { (void)hipFree(c->mesh_indices); c->mesh_indices = nullptr; }
-    VKR_HIP_CHECK(hipMalloc((void **)&c->mesh_verts, (size_t)n_verts * 12));
-    VKR_HIP_CHECK(hipMalloc((void **)&c->mesh_indices, (size_t)n_tris * 12));
-    int32_t rc = upload(c, c->mesh_verts, verts, (size_t)n_verts * 12);
-    if (rc == VKR_OK) rc = upload(c, c->mesh_indices, indices, (size_t)n_tris * 12);
-    if (rc != VKR_OK) return rc;
+    // the new mesh replaces the old one only once it is complete on the device
+    float *new_verts = nullptr;
+    uint32_t *new_indices = nullptr;
+    VKR_HIP_CHECK(hipMalloc((void **)&new_verts, (size_t)n_verts * 12));
+    hipError_t e = hipMalloc((void **)&new_indices, (size_t)n_tris * 12);
+    int32_t rc = e == hipSuccess ? upload(c, new_verts, verts, (size_t)n_verts * 12) : fail(VKR_ERR_HIP, "vkr_set_light_volume_mesh: %s", hipGetErrorString(e));
+    if (rc == VKR_OK) rc = upload(c, new_indices, indices, (size_t)n_tris * 12);
+    if (rc != VKR_OK) { (void)hipFree(new_verts); if (new_indices) (void)hipFree(new_indices); return rc; }
+    VKR_HIP_CHECK(hipStreamSynchronize(c->stream));  // frames that still read the old mesh
+    if (c->mesh_verts) (void)hipFree(c->mesh_verts);
+    if (c->mesh_indices) (void)hipFree(c->mesh_indices);
+    c->mesh_verts = new_verts; c->mesh_indices = new_indices;
     c->mesh_n_verts = n_verts; c->mesh_n_tris = n_tris;
     return VKR_OK;
 }
@@ -546,10 +550,15 @@ extern "C" int32_t vkr_set_mesh_attributes(vkr_ctx *c, int32_t mesh, const float
     VKR_REQUIRE(texcoords && normals && tangents, "vkr_set_mesh_attributes: an attribute array is null");
     vkr_ctx::Mesh &m = c->meshes[mesh];
     const size_t n = (size_t)m.n_verts;
-    if (!m.texcoords) {
-        VKR_HIP_CHECK(hipMalloc((void **)&m.texcoords, n * 8));
-        VKR_HIP_CHECK(hipMalloc((void **)&m.normals, n * 12));
-        VKR_HIP_CHECK(hipMalloc((void **)&m.tangents, n * 12));
+    if (!m.texcoords) {  // all three arrays or none: `texcoords` is what marks a mesh as shadeable
+        float *t = nullptr, *nn = nullptr, *tg = nullptr;
+        if (hipMalloc((void **)&t, n * 8) != hipSuccess || hipMalloc((void **)&nn, n * 12) != hipSuccess || hipMalloc((void **)&tg, n * 12) != hipSuccess) {
+            (void)hipGetLastError();
+            if (t) (void)hipFree(t);
+            if (nn) (void)hipFree(nn);
+            return fail(VKR_ERR_HIP, "vkr_set_mesh_attributes: out of device memory");
+        }
+        m.texcoords = t; m.normals = nn; m.tangents = tg;
     }
     int32_t rc = upload(c, m.texcoords, texcoords, n * 8);
     if (rc == VKR_OK) rc = upload(c, m.normals, normals, n * 12);
@@ -867,7 +876,7 @@ static int32_t clear_stage_attachments(vkr_ctx *c, Frame &f, int32_t stage)
     case VKR_STAGE_BLOOM2: f.bloom2_valid = true; return fill_u64(f.bloom2, px, RGBA16F_0001, c->stream);
     default:
         rc = fill_u64(f.ldr, px / 2, 0xFF000000FF000000ull, c->stream);
-        if (rc == VKR_OK && (px & 1)) VKR_HIP_CHECK(hipMemsetAsync((char *)f.ldr + (px - 1) * 4, 0, 4, c->stream));
+        if (rc == VKR_OK && (px & 1)) VKR_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)((char *)f.ldr + (px - 1) * 4), (int)0xFF000000u, 1, c->stream));
         return rc;
     }
 }
