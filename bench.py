@@ -589,7 +589,9 @@ def main() -> None:
     ap.add_argument("--cpu-rows", type=int, default=None, help="rows of the frame the CPU baseline shades (default: all; 0 = skip)")
     ap.add_argument("--no-ibl", action="store_true", help="skip the IBL precompute timing")
     ap.add_argument("--no-coverage", action="store_true", help="skip the light-volume coverage and shadow-pass timings")
-    ap.add_argument("--no-extra", action="store_true", help="skip the extra shapes (the 16384-wide / 256-light strip; N > 1: also a full strip per rank)")
+    ap.add_argument("--no-extra", action="store_true", help="N > 1: skip the extra shapes (a full strip per rank and the 16384-wide / 256-light strip)")
+    ap.add_argument("--extra", action="store_true", help="N = 1: also time the 16384x2048 / 256-light strip (off by default, so that every launch of the "
+                    "shading kernel in a default run has the shape the roofline is quoted on and a kernel trace of the run averages one shape)")
     ap.add_argument("--transport-only", action="store_true", help="rehearse launcher, halo exchange and gather on CPU tensors (no GPU, no kernels)")
     ap.add_argument("--launch-timeout", type=float, default=900.0, help="seconds the self-started ranks may take")
     args = ap.parse_args()
@@ -664,8 +666,8 @@ def main() -> None:
         torch.cuda.synchronize()
 
     extra = {}
-    if not args.no_extra:
-        # N > 1: a full strip per rank (weak scaling) and the 16384-wide / 256-light strip per rank; N = 1: the latter alone
+    if (world > 1 and not args.no_extra) or (world == 1 and args.extra):
+        # N > 1: a full strip per rank (weak scaling) and the 16384-wide / 256-light strip per rank; N = 1 (--extra): the latter alone
         extra = extra_shapes(args, rank, world, device, scene, dev_frame, weak=world > 1)
         if world > 1:
             dist.barrier()
