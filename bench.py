@@ -701,6 +701,16 @@ def main() -> None:
             roofline["valu_lane_instructions"] = shade_ctr["SQ_INSTS_VALU"] * 64
             roofline["canonical_ops_per_lane_instruction"] = round(flops / (shade_ctr["SQ_INSTS_VALU"] * 64), 3)
         roofline["wave_lights_without_taps_frac"] = shade_ctr.get("wave_lights_without_taps_frac")
+        # how busy the two units are that bound the kernel (same counter file): the 256 texture addressers, against the
+        # cycles the launch was active on an XCD; the vector ALUs, whose busy time is tallied in units of four cycles
+        if shade_ctr.get("TA_TA_BUSY_sum") and shade_ctr.get("GRBM_GUI_ACTIVE"):
+            cycles = shade_ctr["GRBM_GUI_ACTIVE"] / 8
+            roofline["texture_addresser_busy_frac"] = round(shade_ctr["TA_TA_BUSY_sum"] / 256 / cycles, 3)
+            if shade_ctr.get("SQ_INSTS_VMEM_RD"):
+                roofline["gather_instructions"] = int(shade_ctr["SQ_INSTS_VMEM_RD"])
+                roofline["addresser_cycles_per_gather"] = round(shade_ctr["TA_TA_BUSY_sum"] / shade_ctr["SQ_INSTS_VMEM_RD"], 2)
+            if shade_ctr.get("SQ_ACTIVE_INST_VALU"):
+                roofline["valu_busy_frac"] = round(min(shade_ctr["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * cycles), 1.0), 3)
     def hbm_rec(kernel, bytes_per_px, ms, algorithmic, ctr_name):
         gbs = bytes_per_px * strip_px / (ms * 1e-3) / 1e9
         return {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
