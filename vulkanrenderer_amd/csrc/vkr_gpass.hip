@@ -48,6 +48,7 @@ struct GpassParams {
     int n_draws;
     int draw;                   // visibility kernel: the draw of this launch
     unsigned tri_base;          // number of its first triangle in submission order
+    unsigned scatter_stride;    // lane s of the launch takes triangle s * stride mod n (stride coprime to n)
     float vp[16];               // (proj * view), row-vector convention
     int width, rows, frame_rows, row0;
     unsigned long long *vis;
@@ -83,8 +84,13 @@ VKR_DEV void gpass_vertex(const VkrGpassDraw &d, const float *vp, unsigned i, Gp
 __global__ __launch_bounds__(256) void gpass_visibility_kernel(const GpassParams p)
 {
     const VkrGpassDraw &d = p.draws[p.draw];
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    bool have = t < d.n_tris;  // lanes past the end stay: the wave shares large triangles
+    // Lane -> triangle: neighbours in a mesh are neighbours on the screen and of similar size, so with consecutive
+    // triangles per wave the few waves that own the triangles next to the camera would run long after the rest
+    // (there is about one wave per SIMD).  Triangle s * stride mod n for lane s spreads every wave over the mesh;
+    // the stride is coprime to n, so every triangle is taken exactly once.
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    bool have = s < d.n_tris;  // lanes past the end stay: the wave shares large triangles
+    const int t = have ? (int)(((unsigned long long)s * p.scatter_stride) % (unsigned)d.n_tris) : 0;
     float clip[3][4] = {};
     int bx0 = 0, by0 = 0, bx1 = -1, by1 = -1;
     if (have) {
@@ -279,12 +285,13 @@ static int32_t launch_gbuffer(const char *who, const VkrGpassArgs *a, unsigned l
         }
     p.width = a->width; p.rows = a->rows; p.frame_rows = a->frame_rows; p.row0 = a->row0;
     p.albedo = (uint2 *)a->albedo; p.normal = (uint2 *)a->normal; p.arm = (uint2 *)a->arm; p.position = (uint2 *)a->position;
-    p.draw = 0; p.tri_base = 0;
+    p.draw = 0; p.tri_base = 0; p.scatter_stride = 1;
     hipLaunchKernelGGL(fill_u64_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, as_stream(stream), p.vis, npx, ~0ull);
     unsigned base = 0;
     for (int d = 0; d < a->n_draws; d++) {
         if (a->draws[d].n_tris > 0) {
             p.draw = d; p.tri_base = base;
+            p.scatter_stride = scatter_stride_for((unsigned)a->draws[d].n_tris);
             hipLaunchKernelGGL(gpass_visibility_kernel, dim3((unsigned)((a->draws[d].n_tris + 255) / 256)), dim3(256), 0, as_stream(stream), p);
         }
         base += (unsigned)a->draws[d].n_tris;

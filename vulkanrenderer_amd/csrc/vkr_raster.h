@@ -155,4 +155,15 @@ VKR_DEV void raster_boxes(bool have, const float (&clip)[3][4], const float (&at
     }
 }
 
+// A stride coprime to n, near n / golden ratio: consecutive lanes then take triangles far apart in the mesh.
+inline unsigned scatter_stride_for(unsigned n)
+{
+    if (n < 4) return 1;
+    auto gcd = [](unsigned a, unsigned b) { while (b) { unsigned t = a % b; a = b; b = t; } return a; };
+    unsigned s = (unsigned)((double)n * 0.6180339887498949);
+    if (s < 1) s = 1;
+    while (gcd(s, n) != 1) s++;
+    return s;
+}
+
 }  // namespace vkr
