@@ -727,7 +727,7 @@ def main() -> None:
         "unit": "Mpixels/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,  # the same frame at every N (one strip at N = 1)
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{WIDTH}x{HEIGHT} frame" + (f" cut into {world} strips of {plan.rows} rows, one per GPU" if world > 1 else "") +
                                f", {args.lights} point lights with {args.cube_res}^2 cube shadow maps + {args.dir_res}^2 directional PCF shadow; "
