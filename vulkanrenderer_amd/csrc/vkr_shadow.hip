@@ -96,15 +96,18 @@ VKR_DEV void shadow_raster(bool valid, const float (&clip)[3][4], const float (&
     });
 }
 
-__global__ __launch_bounds__(256) void point_shadow_kernel(const ShadowParams p)
+#ifndef VKR_PS_BLOCK
+#define VKR_PS_BLOCK 64
+#endif
+__global__ __launch_bounds__(VKR_PS_BLOCK) void point_shadow_kernel(const ShadowParams p)
 {
     __shared__ float s_m[6][16];
     const int li = blockIdx.y;
     const float *lp = p.lights + (size_t)li * 23 + 16;
     const float eye[3] = {lp[0], lp[1], lp[2]};
-    if (threadIdx.x < 96) shadow_face_matrix_elem(eye, threadIdx.x >> 4, p.far_plane, threadIdx.x & 15, s_m[threadIdx.x >> 4]);
+    for (int e = threadIdx.x; e < 96; e += VKR_PS_BLOCK) shadow_face_matrix_elem(eye, e >> 4, p.far_plane, e & 15, s_m[e >> 4]);
     __syncthreads();
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.x * VKR_PS_BLOCK + threadIdx.x;
     const bool valid = t < p.n_tris;  // lanes past the end stay: the wave shares large triangles
     float world[3][4] = {};
     if (valid) {
@@ -190,7 +193,7 @@ extern "C" int32_t vkr_point_shadow_maps(const VkrPointShadowArgs *a, void *stre
     for (int d = 0; d < a->n_draws; d++) {
         if (a->draws[d].n_tris == 0) continue;
         fill_params(p, a->draws[d]);
-        hipLaunchKernelGGL(point_shadow_kernel, dim3((unsigned)((p.n_tris + 255) / 256), (unsigned)a->n_lights), dim3(256), 0, as_stream(stream), p);
+        hipLaunchKernelGGL(point_shadow_kernel, dim3((unsigned)((p.n_tris + VKR_PS_BLOCK - 1) / VKR_PS_BLOCK), (unsigned)a->n_lights), dim3(VKR_PS_BLOCK), 0, as_stream(stream), p);
     }
     return launch_status("vkr_point_shadow_maps");
 }
