@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 profile set: kernel-trace statistics of the default benchmark, counter passes of the frame chain, of the
+# Profile set: kernel-trace statistics of the default benchmark, counter passes of the frame chain, of the
 # IBL kernels and of the one-kernel post chain, the random-line ceiling.  Everything lands under gpurun_out/r2/.
 set -u
 R=$GRAFT_REPO_ROOT
