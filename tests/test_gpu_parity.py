@@ -978,6 +978,29 @@ def test_gbuffer_bit_exact(gpu, oracle, w, h, row0, frame_rows):
         assert_bits_equal(P.f16_bits(g), wv, f"G-buffer {name}")
 
 
+def test_gbuffer_draws_of_few_triangles(gpu, oracle):
+    """Draws of 1, 2, 3, 5 and 12 triangles cut from the slab (the visibility kernel hands lane s the triangle
+    s * stride mod n: the stride is 1 below four triangles and coprime to n above), overlapping each other, so that
+    equal depths are settled by submission order."""
+    torch, P = _torch(), _passes()
+    w, h = 96, 54
+    verts, tris = synth.make_scene_mesh(6)
+    uv, nrm, tan = synth.mesh_attributes(verts, tris, uv_scale=0.5)
+    draws, start = [], 0
+    for k, n in enumerate((1, 2, 3, 5, 12, 5)):
+        sel = tris[start:start + n] if k < 5 else tris[8:13]   # the last draw repeats triangles of an earlier one
+        start += n if k < 5 else 0
+        alb, nmap, arm = synth.make_material(np.random.default_rng(60 + k), 16)
+        draws.append(dict(positions=verts, texcoords=uv, normals=nrm, tangents=tan, triangles=np.ascontiguousarray(sel), model=np.eye(4),
+                          albedo=alb, normal=nmap, arm=arm))
+    scene = _camera_scene((1.0, 3.0, -3.5), aspect=w / h)
+    want = oracle.gbuffer(draws, scene, w, h, h, 0)
+    assert (want[0][..., 3] != 0).any()
+    got = P.gbuffer(_gpass_device_draws(draws, gpu), scene, w, h, gpu, h, 0)
+    for name, g, wv in zip(("albedo", "normal", "arm", "position"), got, want):
+        assert_bits_equal(P.f16_bits(g), wv, f"G-buffer {name}")
+
+
 def test_whole_frame_from_meshes(gpu, oracle):
     """Meshes in, image out: geometry pass, shadow passes, composition, bloom and tonemap all by the library,
     against the same chain in the oracle."""
