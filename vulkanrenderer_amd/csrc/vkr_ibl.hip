@@ -263,7 +263,10 @@ __global__ __launch_bounds__(256) void prefilter_texel_kernel(const void *env, i
                                                       : normalize3(mk3(0.0f, -N[t].z, N[t].y));  // cross((1,0,0), N)
         bitangent[t] = cross3(N[t], tangent[t]);
     }
-#pragma unroll
+#ifndef VKR_PF_UNROLL
+#define VKR_PF_UNROLL 1
+#endif
+#pragma unroll VKR_PF_UNROLL
     for (int m = 0; m < SAMPLE_COUNT / 256; m++) {
         const int s = tid + 256 * m;
         const float2 pcs = g_hammersley_cs[s];
