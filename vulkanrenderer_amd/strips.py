@@ -180,7 +180,8 @@ class StripRenderer:
     def render(self, frame, volume_mesh=None) -> torch.Tensor:
         """composition of the strip -> halo exchange of its boundary thresholded rows, overlapped with the bloom +
         post-process kernel over the rows that reach no halo row -> the rows next to a neighbour; returns the
-        RGBA8 strip.  With `volume_mesh` each light's draw is limited to the pixels its volume covers; the strip's
+        RGBA8 strip.  With several frames in flight the strip is written on the frame's own stream: synchronize()
+        makes the caller's stream wait for it before the caller reads the tensor.  With `volume_mesh` each light's draw is limited to the pixels its volume covers; the strip's
         place in the frame (plan.row0 of plan.total_rows) enters the projection, nothing is exchanged for it.
 
         The strip is shaded in ONE launch: every wave walks all lights in order, so a launch fills and drains the
