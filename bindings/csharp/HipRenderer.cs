@@ -26,6 +26,8 @@ internal static unsafe class Native
 {
     const string Lib = "vkr_hip";
     [DllImport(Lib)] public static extern sbyte* vkr_last_error();
+    [DllImport(Lib)] public static extern int vkr_abi_version();
+    [DllImport(Lib)] public static extern int vkr_device_count();   // gfx950 devices visible to the process: how many strips a frame can be cut into
     [DllImport(Lib)] public static extern int vkr_create(in VkrConfig config, out nint ctx);
     [DllImport(Lib)] public static extern int vkr_destroy(nint ctx);
     [DllImport(Lib)] public static extern int vkr_resize(nint ctx, int width, int height);
@@ -154,6 +156,7 @@ public sealed unsafe class HipRenderer : IDisposable
     // BeginFrame / UpdateSceneInfo / Lights / DrawModel calls, then
     //     foreach r: r.StripShade();   foreach neighbouring pair: HipRenderer.ExchangeHalo(upper, lower);   foreach r: r.StripFinish();
     // and Read(frame, VKR_TARGET_LDR) of renderer k fills rows [Row0, Row0 + Height) of the image.
+    public static int DeviceCount => Native.vkr_device_count();
     public static (int row0, int rows) StripPlan(int frameRows, int nStrips, int k)
     {
         Check(Native.vkr_strip_plan(frameRows, nStrips, k, out int row0, out int rows));
