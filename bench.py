@@ -396,6 +396,31 @@ def time_ibl(device, reps: int = 3) -> tuple[dict, list]:
     return stages, roof
 
 
+def time_ibl_sharded(rank: int, world: int, device, reps: int = 3) -> dict:
+    """The same precompute with every rank computing an equal share of the rows of the irradiance cube, of each
+    prefilter mip and of the LUT, and the shares all-gathered (every rank needs whole images for shading); the
+    environment cube is resampled on every rank.  Milliseconds per run, slowest rank; all ranks call this."""
+    import torch
+    import torch.distributed as dist
+    from vulkanrenderer_amd import _lib, passes as P, synth
+    from vulkanrenderer_amd.ibl import IblConfig, IblPrecompute
+    cfg = IblConfig(env_res=2048, irradiance_res=64, prefilter_res=128, prefilter_mips=5, lut_res=512)
+    src = P.to_device_f16(synth.make_equirect(np.random.default_rng(SEED + 77), 4096, 2048, hdr=True), device)
+    pre = IblPrecompute(cfg, rank, world, device=device)
+    pre.run(src, _lib.SRC_RGBA16F)
+    torch.cuda.synchronize(); dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = pre.run(src, _lib.SRC_RGBA16F)
+    torch.cuda.synchronize()
+    t = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    del res
+    return {"ms": round(float(t.item()), 3), "world": world,
+            "config": "equirect 4096x2048 -> env 2048^2 on every rank; rows of irradiance 64^2, prefilter 128^2 x5 mips and LUT 512^2 split "
+                      "over the ranks and all-gathered"}
+
+
 def time_coverage(f, dev_frame, renderer, device) -> dict:
     """Light-volume coverage (VKR_COVERAGE_MESH) at the benchmark size: the mask kernel, and the shading kernel
     consuming the masks.  With the reference's light radii every volume contains the camera, so every mask
@@ -662,6 +687,11 @@ def main() -> None:
         else:
             dist.init_process_group(backend)
 
+    def note(msg: str) -> None:  # progress on stderr: a multi-rank run is silent for a minute or more otherwise
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+    note(f"{world} rank(s), backend {backend if world > 1 else 'none'}: building the scene")
     # the frame: every rank builds the same scene and the same whole-frame G-buffer and keeps its own rows
     scene = build_scene(device, args.lights, args.cube_res, args.dir_res)
     whole = frame_of(scene, synth.make_gbuffer(np.random.default_rng(SEED + 1000), WIDTH, HEIGHT), WIDTH, HEIGHT)
@@ -672,6 +702,7 @@ def main() -> None:
     # the gather of frame k overlap the first waves of frame k+1
     renderer = StripRenderer(plan, WIDTH, device=device, frames_in_flight=2)
 
+    note("timed frames")
     elapsed = timed_frames(renderer, dev_frame, world, args.steps, args.warmup, device)
     phases = phase_times(renderer, dev_frame, world, args.steps, device)
     kernel_ms = kernel_times(renderer, dev_frame, plan.rows, args.steps)
@@ -694,11 +725,19 @@ def main() -> None:
         torch.cuda.synchronize()
 
     extra = {}
+    note("extra shapes" if (world > 1 and not args.no_extra) or (world == 1 and args.extra) else "no extra shapes")
     if (world > 1 and not args.no_extra) or (world == 1 and args.extra):
         # N > 1: a full strip per rank (weak scaling) and the 16384-wide / 256-light strip per rank; N = 1 (--extra): the latter alone
         extra = extra_shapes(args, rank, world, device, scene, dev_frame, weak=world > 1)
         if world > 1:
             dist.barrier()
+
+    # N > 1: the IBL precompute with its rows split over the ranks and all-gathered (vulkanrenderer_amd/ibl.py)
+    ibl_sharded = None
+    if world > 1 and not args.no_ibl:
+        note("IBL precompute split over the ranks")
+        ibl_sharded = time_ibl_sharded(rank, world, device)
+    note("per-kernel figures on rank 0")
 
     if rank != 0:
         if world > 1:
@@ -802,6 +841,8 @@ def main() -> None:
                                             "are rendered on every rank).  The G-buffer is the mesh's (geometry_pass_covered_fraction of the pixels carry "
                                             "geometry, the rest shows the skybox), so the composition pass has less to shade here than in the timed step, "
                                             "whose synthetic G-buffer is 90 % covered; sum_of_passes_ms adds the passes timed one by one to the timed step"}
+    if ibl_sharded is not None:
+        out["ibl_precompute_sharded"] = ibl_sharded
     if not args.no_ibl:
         out["ibl_precompute"], out["roofline_ibl"] = time_ibl(device)
     if world == 1 and args.cpu_rows > 0:

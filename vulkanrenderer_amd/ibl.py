@@ -84,6 +84,13 @@ class IblPrecompute:
         if self.world == 1:
             return
         mine = flat[self.rank * per:(self.rank + 1) * per]
+        if flat.is_cuda and dist.get_backend(self.group) == "gloo":
+            # rehearsal on a box with fewer GPUs than ranks: gloo's own staging of device tensors stalls now and then
+            # when ranks share a GPU, so the rows go through host memory here
+            host = flat.cpu()
+            dist.all_gather_into_tensor(host, host[self.rank * per:(self.rank + 1) * per].clone(), group=self.group)
+            flat.copy_(host)
+            return
         dist.all_gather_into_tensor(flat, mine, group=self.group)
 
     def run(self, src: torch.Tensor, src_format: int) -> dict:
