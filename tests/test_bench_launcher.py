@@ -52,7 +52,7 @@ def test_self_launched_ranks_render_one_frame_in_strips(gpu):
     """Two ranks sharing cuda:0 over gloo, HIP kernels, the strong-scaling split of one frame: rank 0's line says
     the gathered image equals the image it renders alone."""
     p = _run("--gpus", "2", "--steps", "2", "--warmup", "1", "--width", "256", "--height", "96", "--lights", "3", "--cube-res", "64",
-             "--dir-res", "128", "--no-ibl", "--no-extra", env={"VKR_DIST_BACKEND": "gloo"})
+             "--dir-res", "128", "--no-extra", env={"VKR_DIST_BACKEND": "gloo"})
     assert p.returncode == 0, p.stderr[-3000:]
     line = _json_line(p.stdout)
     assert line["n_gpus"] == 2 and line["scaling"] == "strong"
@@ -60,3 +60,6 @@ def test_self_launched_ranks_render_one_frame_in_strips(gpu):
     assert line["gathered_equals_single_gpu"] is True
     assert line["value"] > 0 and set(line["phases_ms"]) >= {"halo_wait", "gather", "shade", "interior_bloom_post"}
     assert "48 rows" in line["config"]["workload"]
+    # the IBL precompute with its rows split over the two ranks (2048^2 configuration), and rank 0's own timing of it
+    assert line["ibl_precompute_sharded"]["world"] == 2 and line["ibl_precompute_sharded"]["ms"] > 0
+    assert line["ibl_precompute"]["total_ms"] > 0
