@@ -1102,11 +1102,31 @@ ORC_API void orc_equirect_to_cube(const void *src, int src_w, int src_h, int src
             }
 }
 
+/* The region of the environment cube a LINEAR lookup along r starts in (order = 2 of orc_irradiance): every
+ * face is cut into regions of 512 x 512 texels; a lookup belongs to the region that holds the base texel of
+ * its 2x2 footprint, clamped to the face; regions are numbered (row * per_side + column) * 6 + face. */
+static inline int cube_lookup_region(int n, v3 r)
+{
+    int face; float s, t;
+    cube_st(r, &face, &s, &t);
+    float x = s * (float)n - 0.5f, y = t * (float)n - 0.5f;
+    int i0 = f2i_sat(floorf(x)), j0 = f2i_sat(floorf(y));
+    i0 = i0 < 0 ? 0 : (i0 > n - 1 ? n - 1 : i0);
+    j0 = j0 < 0 ? 0 : (j0 > n - 1 ? n - 1 : j0);
+    int per_side = (n + 511) >> 9;
+    return ((j0 >> 9) * per_side + (i0 >> 9)) * 6 + face;
+}
+
 /* irradiance.frag:10-39.  The loop variables are binary32 running sums, which gives 252 phi
  * values and 63 theta values.  order = 0: one running sum over all samples, phi outer / theta
  * inner, as the shader does.  order = 1: each phi slice is summed on its own (theta ascending,
  * starting from 0) and the slice sums are then added in phi order -- the order a kernel that
- * spreads phi slices over lanes can reproduce bit for bit. */
+ * spreads phi slices over lanes can reproduce bit for bit.  order = 2: the samples are grouped by
+ * the region of the environment their lookup starts in (cube_lookup_region); within a region the
+ * k-th sample (phi outer / theta inner order) goes to accumulator k mod 64, the 64 accumulators are
+ * combined pairwise (partner = index xor 32, 16, 8, 4, 2, 1), and the region sums are added in
+ * region order -- the order a kernel that works through the environment region by region, so that
+ * its lookups hit the cache, can reproduce bit for bit. */
 ORC_API void orc_irradiance(const uint16_t *env, int env_n, uint16_t *out, int n, int order)
 {
     float phis[512], thetas[128];
@@ -1123,7 +1143,35 @@ ORC_API void orc_irradiance(const uint16_t *env, int env_n, uint16_t *out, int n
                 v3 right = normalize3(v3_(N.z, 0.0f, -N.x));
                 v3 up = normalize3(cross3(N, right));
                 float irr[3] = {0, 0, 0};
-                for (int a = 0; a < nphi; a++) {
+                if (order == 2) {
+                    const int per_side = (env_n + 511) >> 9, n_regions = 6 * per_side * per_side;
+                    float (*lanes)[64][3] = calloc((size_t)n_regions, sizeof(*lanes));
+                    int *count = calloc((size_t)n_regions, sizeof(int));
+                    for (int a = 0; a < nphi; a++) {
+                        float cp = cosf(phis[a]), sp = sinf(phis[a]);
+                        for (int b = 0; b < ntheta; b++) {
+                            float st = sinf(thetas[b]), ct = cosf(thetas[b]);
+                            float tx = st * cp, ty = st * sp, tz = ct;
+                            v3 sv = v3_(fmaf(tz, N.x, fmaf(ty, up.x, tx * right.x)),
+                                        fmaf(tz, N.y, fmaf(ty, up.y, tx * right.y)),
+                                        fmaf(tz, N.z, fmaf(ty, up.z, tx * right.z)));
+                            v3 c = texcube_rgb_linear(env, env_n, sv);
+                            int r = cube_lookup_region(env_n, sv);
+                            float *acc = lanes[r][count[r]++ & 63];
+                            acc[0] = fmaf(c.x * ct, st, acc[0]);
+                            acc[1] = fmaf(c.y * ct, st, acc[1]);
+                            acc[2] = fmaf(c.z * ct, st, acc[2]);
+                        }
+                    }
+                    for (int r = 0; r < n_regions; r++) {
+                        for (int d = 32; d >= 1; d >>= 1)
+                            for (int l = 0; l < d; l++)   /* every lane adds its partner: lanes l and l ^ d end up equal */
+                                for (int k = 0; k < 3; k++) lanes[r][l][k] = lanes[r][l][k] + lanes[r][l ^ d][k];
+                        for (int k = 0; k < 3; k++) irr[k] = irr[k] + lanes[r][0][k];
+                    }
+                    free(lanes); free(count);
+                }
+                for (int a = 0; a < nphi && order != 2; a++) {
                     float cp = cosf(phis[a]), sp = sinf(phis[a]);
                     float part[3] = {0, 0, 0};
                     float *acc = order ? part : irr;

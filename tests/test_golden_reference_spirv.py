@@ -69,9 +69,10 @@ def test_ibl_shaders(oracle):
     irr = oracle.f16_to_f32(oracle.irradiance(g["env"], 2, 0))
     for (f, i, j), want in zip(g["irradiance_texels"], g["irradiance"]):
         assert close(irr[f, j, i], want).all(), (f, i, j, irr[f, j, i], want)
-    irr1 = oracle.f16_to_f32(oracle.irradiance(g["env"], 2, 1))   # the phi-slice summation order
-    for (f, i, j), want in zip(g["irradiance_texels"], g["irradiance"]):
-        assert close(irr1[f, j, i], want).all()
+    for order in (1, 2):   # the phi-slice and the by-region summation orders
+        irr1 = oracle.f16_to_f32(oracle.irradiance(g["env"], 2, order))
+        for (f, i, j), want in zip(g["irradiance_texels"], g["irradiance"]):
+            assert close(irr1[f, j, i], want).all(), order
 
     pref = {}
     for (r, f, i, j), want in zip(g["prefilter_cases"], g["prefilter"]):

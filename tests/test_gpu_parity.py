@@ -124,7 +124,7 @@ def test_post_chain_and_ibl_against_reference_shader_vectors(gpu):
     assert close(cube.float().cpu().numpy(), g["equirect_cube"]).all()
     env = P.to_device_f16(g["env"], gpu)
     irr = torch.empty((6, 2, 2, 4), dtype=torch.float16, device=gpu)
-    for order in (_lib.IRRADIANCE_SEQUENTIAL, _lib.IRRADIANCE_PHI_SLICES):
+    for order in (_lib.IRRADIANCE_SEQUENTIAL, _lib.IRRADIANCE_PHI_SLICES, _lib.IRRADIANCE_BY_REGION):
         P.irradiance(env, irr, order)
         got = irr.float().cpu().numpy()
         for (f, i, j), want in zip(g["irradiance_texels"], g["irradiance"]):
@@ -278,7 +278,7 @@ def test_prefilter_bit_exact(gpu, oracle, rough):
     assert_bits_equal(P.f16_bits(out), want, f"prefilter roughness {rough}")
 
 
-@pytest.mark.parametrize("order", [0, 1])
+@pytest.mark.parametrize("order", [0, 1, 2])
 def test_irradiance_bit_exact(gpu, oracle, order):
     torch, P = _torch(), _passes()
     env = synth.make_env_cube(np.random.default_rng(4), 16)
@@ -286,6 +286,48 @@ def test_irradiance_bit_exact(gpu, oracle, order):
     out = torch.empty((6, 4, 4, 4), dtype=torch.float16, device=gpu)
     P.irradiance(P.to_device_f16(env, gpu), out, order)
     assert_bits_equal(P.f16_bits(out), want, f"irradiance order {order}")
+
+
+def test_irradiance_by_region_of_a_large_environment(gpu, oracle):
+    """The by-region order where a face has several regions (1024^2 faces: 2 x 2 regions of 512^2 on each), a last
+    region that is cut short (640^2: regions of 512 and 128 texels), rows of one rank, a workspace that is reused,
+    too small or missing, and the word that counts texels with samples unaccounted for."""
+    torch, P = _torch(), _passes()
+    lib = _lib.load()
+    for env_n, n, tiled in ((1024, 4, True), (640, 3, False), (1024, 3, False)):
+        env = synth.make_env_cube(np.random.default_rng(env_n + n), env_n)
+        dev_env = P.to_device_f16(env, gpu)
+        layout = _lib.ENV_LAYOUT_LINEAR
+        if tiled:
+            dev_env, layout = P.tile_env_cube(dev_env), _lib.ENV_LAYOUT_TILED_4X4
+        want = oracle.irradiance(env, n, 2)
+        out = torch.zeros((6, n, n, 4), dtype=torch.float16, device=gpu)
+        ws = P.irradiance_by_region(dev_env, out, env_layout=layout)
+        assert P.irradiance_uncovered(ws) == 0
+        assert_bits_equal(P.f16_bits(out), want, f"irradiance by region, environment {env_n}, cube {n}")
+        # it is the shader's sum but for rounding: half a binary16 ulp of rounding error in the sum, then the store
+        seq = oracle.f16_to_f32(oracle.irradiance(env, n, 0))
+        got = out.float().cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(seq))   # odd n: the centre texels of the +-Y faces have no frame
+        assert (np.isnan(seq) | (np.abs(got - seq) <= 1.0 * f16_ulp(seq))).all()
+        # rows [r0, r1) only, into an image that holds something else, reusing the (larger) workspace
+        r0, r1 = n + 1, 4 * n - 1
+        part = torch.full((6, n, n, 4), 7.0, dtype=torch.float16, device=gpu)
+        P.irradiance_by_region(dev_env, part, (r0, r1), layout, workspace=ws)
+        need = lib.vkr_ibl_irradiance_by_region_workspace_bytes(env_n, n, r0, r1)
+        assert 0 < need <= ws.numel() and P.irradiance_uncovered(ws, need) == 0
+        got = P.f16_bits(part).reshape(6 * n, n, 4)
+        assert np.array_equal(got[r0:r1], want.reshape(6 * n, n, 4)[r0:r1])
+        assert (part.view(6 * n, n, 4)[:r0] == 7.0).all() and (part.view(6 * n, n, 4)[r1:] == 7.0).all()
+        with pytest.raises(_lib.VkrError):
+            P.irradiance_by_region(dev_env, out, env_layout=layout, workspace=ws[:need - 1])
+    with pytest.raises(_lib.VkrError):
+        _lib.check(lib.vkr_ibl_irradiance(P._ptr(dev_env), env_n, layout, P._ptr(out), n, 2, 0, 6 * n, None))
+    assert lib.vkr_ibl_irradiance_by_region_workspace_bytes(0, 4, 0, 24) == -1
+    assert lib.vkr_ibl_irradiance_by_region_workspace_bytes(64, 4, 0, 25) == -1
+    empty = torch.zeros((6, n, n, 4), dtype=torch.float16, device=gpu)
+    P.irradiance_by_region(dev_env, empty, (5, 5), layout)  # no rows: nothing is written
+    assert (empty == 0).all()
 
 
 @pytest.mark.parametrize("hdr", [True, False])
@@ -610,7 +652,7 @@ def test_tiled_environment_cube(gpu, oracle):
 
     T = _lib.ENV_LAYOUT_TILED_4X4
     irr = torch.empty((6, 8, 8, 4), dtype=torch.float16, device=gpu)
-    for order in (0, 1):
+    for order in (0, 1, 2):
         P.irradiance(tiled, irr, order, env_layout=T)
         assert_bits_equal(P.f16_bits(irr), oracle.irradiance(env, 8, order), f"irradiance from the tiled cube, order {order}")
     pre = torch.empty((6, 16, 16, 4), dtype=torch.float16, device=gpu)

@@ -102,7 +102,7 @@ def test_aces_and_gamma(oracle):
 def test_irradiance_of_constant_environment(oracle):
     # irradiance.frag:21-36: 252 x 63 samples; PI * c * mean(cos*sin) = 0.99708 c
     env = const_cube(8, (0.5, 1.0, 2.0))
-    for order in (0, 1):
+    for order in (0, 1, 2):
         out = oracle.f16_to_f32(oracle.irradiance(env, 2, order))
         assert np.allclose(out[..., :3], np.array([0.5, 1.0, 2.0]) * 0.99708, rtol=2e-3)
         assert (out[..., 3] == 1.0).all()
@@ -113,6 +113,14 @@ def test_irradiance_orders_agree_to_rounding(oracle):
     a = oracle.f16_to_f32(oracle.irradiance(env, 2, 0))
     b = oracle.f16_to_f32(oracle.irradiance(env, 2, 1))
     assert np.allclose(a, b, rtol=2e-3, atol=1e-4)
+    c = oracle.f16_to_f32(oracle.irradiance(env, 2, 2))
+    assert np.allclose(a, c, rtol=2e-3, atol=1e-4)
+    # faces of several regions each (order 2 groups the samples by 512 x 512-texel region; 520^2: regions of 512 and 8)
+    env = synth.make_env_cube(np.random.default_rng(3), 520)
+    a = oracle.f16_to_f32(oracle.irradiance(env, 1, 0))
+    c = oracle.f16_to_f32(oracle.irradiance(env, 1, 2))
+    assert np.isnan(a[2:4, ..., :3]).all()   # N = (0, +-1, 0): cross(up, N) = 0, the shader's frame is NaN
+    assert np.allclose(a, c, rtol=1e-3, atol=1e-4, equal_nan=True)
 
 
 def test_prefilter_of_constant_environment_and_mip0(oracle):

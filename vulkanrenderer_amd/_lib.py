@@ -21,7 +21,7 @@ WRAP_REPEAT, WRAP_CLAMP = 0, 1
 SRC_RGBA8_SRGB, SRC_RGBA16F = 0, 1
 POST_SRGB_TARGET = 1
 GBUFFER_STATIC_MAX_PIXELS, GBUFFER_STATIC_MAX_DRAWS = 2097152, 64
-IRRADIANCE_SEQUENTIAL, IRRADIANCE_PHI_SLICES = 0, 1
+IRRADIANCE_SEQUENTIAL, IRRADIANCE_PHI_SLICES, IRRADIANCE_BY_REGION = 0, 1, 2
 (TARGET_COLOR, TARGET_THRESHOLD, TARGET_BLOOM1, TARGET_BLOOM2, TARGET_LDR,
  TARGET_ENV, TARGET_IRRADIANCE, TARGET_PREFILTER, TARGET_BRDF_LUT) = range(9)
 (STAGE_POINT_SHADOW, STAGE_GEOMETRY, STAGE_DIR_SHADOW, STAGE_COMPOSITION, STAGE_BLOOM1, STAGE_BLOOM2, STAGE_POSTPROCESS) = range(7)
@@ -160,6 +160,8 @@ PROTOTYPES = {
     "vkr_bloom_postprocess": [C.POINTER(BloomChainArgs), _vp],
     "vkr_ibl_equirect_to_cube": [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp],
     "vkr_ibl_irradiance": [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp],
+    "vkr_ibl_irradiance_by_region": [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, C.c_int64, _vp],
+    "vkr_ibl_irradiance_by_region_workspace_bytes": [_i32, _i32, _i32, _i32],
     "vkr_ibl_prefilter": [_vp, _i32, _i32, _vp, _i32, _f, _i32, _i32, _vp],
     "vkr_tile_rgba16f_faces": [_vp, _vp, _i32, _i32, _vp],
     "vkr_measure_peaks": [C.POINTER(C.c_float), C.POINTER(C.c_float)],
@@ -211,7 +213,7 @@ PROTOTYPES = {
 _lib = None
 
 
-RETURNS_INT64 = {"vkr_gbuffer_workspace_bytes"}
+RETURNS_INT64 = {"vkr_gbuffer_workspace_bytes", "vkr_ibl_irradiance_by_region_workspace_bytes"}
 
 
 def load() -> C.CDLL:

@@ -693,7 +693,25 @@ extern "C" int32_t vkr_create_irradiance_cubemap(vkr_ctx *c, int32_t order)
     if (!c->have_env) return fail(VKR_ERR_ORDER, "vkr_create_irradiance_cubemap: no environment cube yet");
     const void *env = c->env_tiled ? c->env_tiled : c->env;
     const int32_t layout = c->env_tiled ? VKR_ENV_LAYOUT_TILED_4X4 : VKR_ENV_LAYOUT_LINEAR;
-    int32_t rc = vkr_ibl_irradiance(env, c->cfg.env_res, layout, c->irradiance, c->cfg.irradiance_res, order, 0, 6 * c->cfg.irradiance_res, c->stream);
+    const int32_t n = c->cfg.irradiance_res;
+    if (order == VKR_IRRADIANCE_BY_REGION) {
+        // a one-off step: its workspace lives for this call only
+        const int64_t bytes = vkr_ibl_irradiance_by_region_workspace_bytes(c->cfg.env_res, n, 0, 6 * n);
+        if (bytes < 0) return VKR_ERR_INVALID;
+        void *ws = nullptr;
+        VKR_HIP_CHECK(hipMalloc(&ws, (size_t)bytes));
+        int32_t rc = vkr_ibl_irradiance_by_region(env, c->cfg.env_res, layout, c->irradiance, n, 0, 6 * n, ws, bytes, c->stream);
+        uint32_t uncovered = 0;
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (rc == VKR_OK && e == hipSuccess) e = hipMemcpy(&uncovered, (const char *)ws + bytes - 256, 4, hipMemcpyDeviceToHost);
+        (void)hipFree(ws);
+        if (rc != VKR_OK) return rc;
+        if (e != hipSuccess) return fail(VKR_ERR_HIP, "vkr_create_irradiance_cubemap: %s", hipGetErrorString(e));
+        if (uncovered != 0) return fail(VKR_ERR_HIP, "vkr_create_irradiance_cubemap: %u texels did not find all of their samples", uncovered);
+        c->have_irr = true;
+        return VKR_OK;
+    }
+    int32_t rc = vkr_ibl_irradiance(env, c->cfg.env_res, layout, c->irradiance, n, order, 0, 6 * n, c->stream);
     if (rc != VKR_OK) return rc;
     VKR_HIP_CHECK(hipStreamSynchronize(c->stream));
     c->have_irr = true;

@@ -143,16 +143,28 @@ template <bool TILED> VKR_DEV size_t cube_texel_index(int n, int f, int i, int j
     return face0 + (((unsigned)j >> 2) * ((unsigned)n >> 2) + ((unsigned)i >> 2)) * 16u + ((unsigned)j & 3u) * 4u + ((unsigned)i & 3u);
 }
 
-// LINEAR, seamless lookup in an RGBA16F cube, mip 0 (textureSampler on a one-level cube view)
-template <bool TILED = false>
-VKR_DEV f3 texcube_rgb_linear(const void *cube, int n, f3 r)
+// Footprint of a LINEAR lookup in a cube of face size n: the face, the base texel (i0, j0) of the 2x2 texels
+// (either may be -1 or n - 1: the footprint then reaches over a face edge) and the two interpolation weights.
+struct cube_footprint { int face, i0, j0; float al, be; };
+VKR_DEV cube_footprint cube_linear_footprint(int n, f3 r)
 {
-    int face; float s, t;
-    cube_st(r, face, s, t);
+    cube_footprint p;
+    float s, t;
+    cube_st(r, p.face, s, t);
     float x = s * (float)n - 0.5f, y = t * (float)n - 0.5f;
     float fx = __builtin_floorf(x), fy = __builtin_floorf(y);
-    float al = x - fx, be = y - fy;
-    int i0 = (int)fx, j0 = (int)fy;
+    p.al = x - fx; p.be = y - fy;
+    p.i0 = (int)fx; p.j0 = (int)fy;
+    return p;
+}
+
+// The four texels of a footprint, weighted (seamless over face edges; at a cube corner the missing texel is the
+// mean of the other three).
+template <bool TILED>
+VKR_DEV f3 texcube_fetch_footprint(const void *cube, int n, cube_footprint p)
+{
+    const int face = p.face, i0 = p.i0, j0 = p.j0;
+    const float al = p.al, be = p.be;
     float w0 = (1.0f - al) * (1.0f - be), w1 = al * (1.0f - be), w2 = (1.0f - al) * be, w3 = al * be;
     const uint2 *base = (const uint2 *)cube;
     rgba t0, t1, t2, t3;
@@ -192,6 +204,13 @@ VKR_DEV f3 texcube_rgb_linear(const void *cube, int n, f3 r)
                fma_(w3, t3.b, fma_(w2, t2.b, fma_(w1, t1.b, w0 * t0.b))));
 }
 
+// LINEAR, seamless lookup in an RGBA16F cube, mip 0 (textureSampler on a one-level cube view)
+template <bool TILED = false>
+VKR_DEV f3 texcube_rgb_linear(const void *cube, int n, f3 r)
+{
+    return texcube_fetch_footprint<TILED>(cube, n, cube_linear_footprint(n, r));
+}
+
 VKR_DEV int wrap_repeat(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
 // The same for a coordinate known to be within one period of [0, n) (anything else takes the division)
 VKR_DEV int wrap_near(int i, int n)
@@ -200,11 +219,9 @@ VKR_DEV int wrap_near(int i, int n)
     return i < 0 ? i + n : (i >= n ? i - n : i);
 }
 
-// Direction through the centre of texel (i,j) of face f of an n^2 cube (inverse of cube_face)
-VKR_DEV f3 face_dir(int f, int i, int j, int n)
+// Point (s, t) in [-1, 1]^2 of face f as a direction (inverse of cube_face)
+VKR_DEV f3 face_point(int f, float s, float t)
 {
-    float rn = rcp_rn((float)n);
-    float s = fma_((float)(2 * i + 1), rn, -1.0f), t = fma_((float)(2 * j + 1), rn, -1.0f);
     switch (f) {
     case 0: return mk3(1.0f, -t, -s);
     case 1: return mk3(-1.0f, -t, s);
@@ -213,6 +230,14 @@ VKR_DEV f3 face_dir(int f, int i, int j, int n)
     case 4: return mk3(s, -t, 1.0f);
     default: return mk3(-s, -t, -1.0f);
     }
+}
+
+// Direction through the centre of texel (i,j) of face f of an n^2 cube
+VKR_DEV f3 face_dir(int f, int i, int j, int n)
+{
+    float rn = rcp_rn((float)n);
+    float s = fma_((float)(2 * i + 1), rn, -1.0f), t = fma_((float)(2 * j + 1), rn, -1.0f);
+    return face_point(f, s, t);
 }
 
 }  // namespace vkr

@@ -218,6 +218,205 @@ __global__ __launch_bounds__(256) void irradiance_slices_kernel(const void *env,
     }
 }
 
+// ---- irradiance.frag:10-39, summed by region of the environment -------------------------------
+//
+// A sample of an output texel lands 32 environment texels from the next one (at 2048^2 faces), so a texel's own
+// samples share no cache lines and the kernels above miss L2 more than once per lookup.  Here the environment is cut
+// into regions of 512^2 texels (2 MiB, half of one XCD's L2) and the work is ordered by region: a workgroup takes one
+// region and IRR_GROUP output texels, finds for each texel the samples whose footprint starts in the region, fetches
+// them (from L2: every workgroup resident on an XCD reads the same region) and adds them up.  The sum of a (texel,
+// region) pair is defined so that a wave can form it without sorting anything: the pair's k-th sample in the
+// shader's order (phi outer, theta inner) goes to accumulator k mod 64 (lane k mod 64), and the 64 accumulators are
+// combined pairwise with the partners 32, 16, 8, 4, 2, 1 lanes away.  irradiance_regions_sum_kernel then adds a
+// texel's region sums in region order.  The result differs from the single running sum in rounding only.
+//
+// Which samples of texel N land in a region: in N's tangent frame the region lies inside a cone (centre c, half
+// angle alpha) at polar angle acos(c.N) and azimuth atan2(c.up, c.right); samples outside the index box that
+// cone spans (plus a margin of one index and 0.004 rad) cannot land in it.  Every cell of the box is then decided
+// exactly: the sample's direction and footprint are computed with the arithmetic of the other kernels, and the
+// sample belongs to the region that holds the footprint's base texel (clamped to the face).  A sample has one such
+// region, so it is counted exactly once; the count of samples found travels with the sums, and a texel whose
+// count is not nphi * ntheta is reported.
+static constexpr int IRR_GROUP = 64;         // output texels per workgroup
+static constexpr int IRR_QUEUE = 128;        // entries of a wave's queue of samples to fetch (a ring; at most 63 + 64 are held)
+static constexpr int IRR_REGION_SHIFT = 9;   // regions of 512 x 512 texels
+static constexpr float IRR_STEP = 0.025f;    // irradiance.frag:19, sampleDelta
+static constexpr float IRR_MARGIN = 0.004f;  // radians added to a region's cone
+
+struct irr_box { int a0, na, b0, nb; };  // phi indices a0 .. a0+na-1 (mod nphi), theta indices b0 .. b0+nb-1
+
+// partial: [region][4][texels_padded] -- red, green, blue sums and the number of samples, texels_padded = n_groups * IRR_GROUP
+template <bool TILED>
+__global__ __launch_bounds__(256) void irradiance_region_kernel(const void *env, int env_n, int n, int nphi, int ntheta, int row_begin, int n_texels,
+                                                                float *partial, int regions_per_side, int n_regions, int n_groups)
+{
+    __shared__ float2 phi_cs[IRR_MAX_PHI], theta_sc[IRR_MAX_THETA];
+    __shared__ float frame[IRR_GROUP][9];
+    __shared__ irr_box box[IRR_GROUP];
+    __shared__ uint32_t q_pk[4][IRR_QUEUE], q_b[4][IRR_QUEUE];
+    __shared__ float q_al[4][IRR_QUEUE], q_be[4][IRR_QUEUE];
+    __shared__ float sums[4][IRR_GROUP];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // workgroups go to the XCDs round-robin by id: XCD x works through regions x, x + 8, ... one after the other
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int region = (k / n_groups) * 8 + xcd, group = k % n_groups;
+    if (region >= n_regions) return;
+    const int rf = region % 6, cell = region / 6;
+    const int rx = cell % regions_per_side, ry = cell / regions_per_side;
+    for (int t = tid; t < nphi; t += 256) phi_cs[t] = g_irr_phi_cs[t];
+    if (tid < ntheta) theta_sc[tid] = g_irr_theta_sc[tid];
+    if (tid < IRR_GROUP) {
+        const int idx = min(group * IRR_GROUP + tid, n_texels - 1);
+        const int row = row_begin + idx / n, i = idx % n;
+        const int f = row / n, j = row - f * n;
+        const f3 N = normalize3(face_dir(f, i, j, n));
+        const f3 right = normalize3(mk3(N.z, 0.0f, -N.x));  // normalize(cross((0,1,0), N))
+        const f3 up = normalize3(cross3(N, right));
+        float *fr = frame[tid];
+        fr[0] = N.x; fr[1] = N.y; fr[2] = N.z; fr[3] = right.x; fr[4] = right.y; fr[5] = right.z; fr[6] = up.x; fr[7] = up.y; fr[8] = up.z;
+        // the region in face coordinates: base texel i0 = floor(s n - 1/2) in [x0, x1), the first and last regions
+        // also take what the clamp sends them
+        const float rn = 1.0f / (float)env_n;
+        const int x0 = rx << IRR_REGION_SHIFT, x1 = min((rx + 1) << IRR_REGION_SHIFT, env_n), y0 = ry << IRR_REGION_SHIFT, y1 = min((ry + 1) << IRR_REGION_SHIFT, env_n);
+        const float u0 = x0 == 0 ? -1.0f : (float)(2 * x0 + 1) * rn - 1.0f, u1 = x1 == env_n ? 1.0f : (float)(2 * x1 + 1) * rn - 1.0f;
+        const float v0 = y0 == 0 ? -1.0f : (float)(2 * y0 + 1) * rn - 1.0f, v1 = y1 == env_n ? 1.0f : (float)(2 * y1 + 1) * rn - 1.0f;
+        const f3 c = normalize3(face_point(rf, 0.5f * (u0 + u1), 0.5f * (v0 + v1)));
+        float cosa = dot3(c, normalize3(face_point(rf, u0, v0)));
+        cosa = fminf(cosa, dot3(c, normalize3(face_point(rf, u1, v0))));
+        cosa = fminf(cosa, dot3(c, normalize3(face_point(rf, u0, v1))));
+        cosa = fminf(cosa, dot3(c, normalize3(face_point(rf, u1, v1))));
+        const float alpha = acosf(fminf(cosa, 1.0f)) + IRR_MARGIN;
+        const float thc = acosf(fminf(fmaxf(dot3(c, N), -1.0f), 1.0f));
+        irr_box bx; bx.a0 = 0; bx.na = 0; bx.b0 = 0; bx.nb = 0;
+        // N = (0, +-1, 0) has no tangent frame (right = normalize(0) is NaN, as in the shader): every sample direction
+        // is then NaN, which the lookup takes to one region; no cone can be drawn, so every region looks at all samples
+        const float frame_sum = ((right.x + right.y) + right.z) + ((up.x + up.y) + up.z);
+        if (group * IRR_GROUP + tid < n_texels && !(frame_sum == frame_sum)) {
+            bx.na = nphi; bx.nb = ntheta;
+        } else if (group * IRR_GROUP + tid < n_texels && thc - alpha < 0.5f * PI_F) {
+            const float inv = 1.0f / IRR_STEP;
+            bx.b0 = max(0, (int)floorf((thc - alpha) * inv) - 1);
+            bx.nb = min(ntheta - 1, (int)floorf((thc + alpha) * inv) + 1) - bx.b0 + 1;
+            const float sa = sinf(alpha), sth = sinf(thc);
+            bool full = thc <= alpha || sa >= 0.999f * sth;
+            int alo = 0, ahi = 0;
+            float lo = 0.0f, hi = 0.0f;
+            if (!full) {
+                const float dphi = asinf(fminf(sa / sth, 1.0f)) + IRR_MARGIN;
+                float phc = atan2f(dot3(c, up), dot3(c, right));
+                if (phc < 0.0f) phc += 2.0f * PI_F;
+                lo = phc - dphi; hi = phc + dphi;
+                alo = (int)floorf(lo * inv) - 1; ahi = (int)floorf(hi * inv) + 1;
+                full = ahi - alo + 1 >= nphi;
+            }
+            if (!full) {
+                if (alo < 0) {  // phi in [lo + 2 pi, 2 pi) and in [0, hi]
+                    const int w0 = min((int)floorf((lo + 2.0f * PI_F) * inv) - 1, nphi);
+                    if (w0 <= ahi + 1) full = true;
+                    else { bx.a0 = w0; bx.na = (nphi - w0) + (ahi + 1); }
+                } else if (ahi >= nphi) {  // phi in [lo, 2 pi) and in [0, hi - 2 pi]
+                    const int e = max((int)floorf((hi - 2.0f * PI_F) * inv) + 1, -1);
+                    if (e >= alo - 1) full = true;
+                    else { bx.a0 = alo; bx.na = (nphi - alo) + (e + 1); }
+                } else { bx.a0 = alo; bx.na = ahi - alo + 1; }
+            }
+            if (full || bx.na >= nphi) { bx.a0 = 0; bx.na = nphi; }
+            if (bx.nb <= 0) bx.na = 0;
+        }
+        box[tid] = bx;
+    }
+    __syncthreads();
+    // Samples that land in the region are queued per wave (footprint and theta index) and fetched 64 at a time, so
+    // that the lanes of a fetch are in use whatever share of a box's cells hit; queue entry k of a pair is fetched
+    // and accumulated by lane k mod 64.
+    for (int t = w; t < IRR_GROUP; t += 4) {
+        const int na = __builtin_amdgcn_readfirstlane(box[t].na);
+        float sr = 0.0f, sg = 0.0f, sb = 0.0f;
+        int found = 0;
+        if (na != 0) {
+            const int a0 = __builtin_amdgcn_readfirstlane(box[t].a0), b0 = __builtin_amdgcn_readfirstlane(box[t].b0), nb = __builtin_amdgcn_readfirstlane(box[t].nb);
+            const float *fr = frame[t];
+            const f3 N = mk3(fr[0], fr[1], fr[2]), right = mk3(fr[3], fr[4], fr[5]), up = mk3(fr[6], fr[7], fr[8]);
+            const float inv_nb = 1.0f / (float)nb;
+            const int cells = na * nb;
+            // a box that runs over the end of the phi range is walked from phi index 0: the part that wrapped comes first
+            const int wrapped = max(a0 + na - nphi, 0);
+            int q_head = 0, q_count = 0;
+            auto drain = [&](int count) {
+                if (lane < count) {
+                    const int e = (q_head + lane) & (IRR_QUEUE - 1);
+                    const uint32_t pk = q_pk[w][e];
+                    cube_footprint fp;
+                    fp.face = rf; fp.i0 = (int)(pk & 0xFFFFu) - 1; fp.j0 = (int)(pk >> 16) - 1; fp.al = q_al[w][e]; fp.be = q_be[w][e];
+                    const float2 tsc = theta_sc[q_b[w][e]];
+                    const f3 c = texcube_fetch_footprint<TILED>(env, env_n, fp);
+                    sr = fma_(c.x * tsc.y, tsc.x, sr);
+                    sg = fma_(c.y * tsc.y, tsc.x, sg);
+                    sb = fma_(c.z * tsc.y, tsc.x, sb);
+                }
+            };
+            for (int base = 0; base < cells; base += 64) {
+                const bool live = base + lane < cells;
+                const int kk = min(base + lane, cells - 1);
+                // kk / nb: (kk + 1/2) / nb is at least 1/(2 nb) >= 0.0079 from an integer, the product's error is below 0.002
+                const int q = (int)(((float)kk + 0.5f) * inv_nb);
+                const int b = b0 + (kk - q * nb);
+                const int a = q < wrapped ? q : a0 + (q - wrapped);
+                const float2 pcs = phi_cs[a], tsc = theta_sc[b];
+                const float st = tsc.x, ct = tsc.y;
+                const float tx = st * pcs.x, ty = st * pcs.y, tz = ct;
+                const f3 sv = mk3(fma_(tz, N.x, fma_(ty, up.x, tx * right.x)),
+                                  fma_(tz, N.y, fma_(ty, up.y, tx * right.y)),
+                                  fma_(tz, N.z, fma_(ty, up.z, tx * right.z)));
+                const cube_footprint fp = cube_linear_footprint(env_n, sv);
+                const int ic = min(max(fp.i0, 0), env_n - 1) >> IRR_REGION_SHIFT, jc = min(max(fp.j0, 0), env_n - 1) >> IRR_REGION_SHIFT;
+                const bool hit = live && fp.face == rf && ic == rx && jc == ry;
+                const uint64_t m = __ballot(hit);
+                if (hit) {
+                    const int e = (q_head + q_count + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))) & (IRR_QUEUE - 1);
+                    q_pk[w][e] = (uint32_t)(fp.i0 + 1) | ((uint32_t)(fp.j0 + 1) << 16);
+                    q_al[w][e] = fp.al; q_be[w][e] = fp.be; q_b[w][e] = (uint32_t)b;
+                }
+                const int hits = __popcll(m);
+                q_count += hits; found += hits;
+                if (q_count >= 64) {
+                    drain(64);
+                    q_head = (q_head + 64) & (IRR_QUEUE - 1);
+                    q_count -= 64;
+                }
+            }
+            drain(q_count);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                sr += __shfl_xor(sr, d, 64); sg += __shfl_xor(sg, d, 64); sb += __shfl_xor(sb, d, 64);
+            }
+        }
+        if (lane == 0) { sums[0][t] = sr; sums[1][t] = sg; sums[2][t] = sb; sums[3][t] = (float)found; }
+    }
+    __syncthreads();
+    const size_t padded = (size_t)n_groups * IRR_GROUP;
+    partial[((size_t)region * 4 + w) * padded + (size_t)group * IRR_GROUP + lane] = sums[w][lane];
+}
+
+// Adds the region sums of every output texel in region order; *uncovered counts the texels whose samples were not
+// all found by irradiance_region_kernel (none, unless its cone test has a flaw).
+__global__ __launch_bounds__(256) void irradiance_regions_sum_kernel(const float *partial, int n_regions, int n_groups, uint2 *out, int n, int nphi, int ntheta,
+                                                                     int row_begin, int n_texels, uint32_t *uncovered)
+{
+    const int texel = blockIdx.x * 256 + threadIdx.x;
+    if (texel >= n_texels) return;
+    const size_t padded = (size_t)n_groups * IRR_GROUP;
+    float r = 0.0f, g = 0.0f, b = 0.0f, found = 0.0f;
+    for (int k = 0; k < n_regions; k++) {
+        const float *p = partial + (size_t)k * 4 * padded + texel;
+        r += p[0]; g += p[padded]; b += p[2 * padded]; found += p[3 * padded];
+    }
+    const int count = nphi * ntheta;
+    if (found != (float)count) atomicAdd(uncovered, 1u);
+    const float inv_count = rcp_rn((float)count);
+    out[(size_t)row_begin * n + texel] = pack4((PI_F * r) * inv_count, (PI_F * g) * inv_count, (PI_F * b) * inv_count, 1.0f);
+}
+
 // ---- prefilter.frag / brdf.frag shared pieces -----------------------------------------------
 
 // prefilter.frag:65-73
@@ -447,6 +646,7 @@ extern "C" int32_t vkr_ibl_irradiance(const void *env, int32_t env_n, int32_t en
 {
     using namespace vkr;
     VKR_REQUIRE(env && out && env_n > 0, "vkr_ibl_irradiance: an image is null or env size is bad");
+    VKR_REQUIRE(order != VKR_IRRADIANCE_BY_REGION, "vkr_ibl_irradiance: the by-region order needs a workspace, call vkr_ibl_irradiance_by_region");
     VKR_REQUIRE(order == VKR_IRRADIANCE_SEQUENTIAL || order == VKR_IRRADIANCE_PHI_SLICES, "vkr_ibl_irradiance: unknown summation order %d", order);
     int32_t rc = check_rows("vkr_ibl_irradiance", n, 6 * n, row_begin, row_end);
     if (rc != VKR_OK) return rc;
@@ -462,6 +662,57 @@ extern "C" int32_t vkr_ibl_irradiance(const void *env, int32_t env_n, int32_t en
         hipLaunchKernelGGL(tiled ? irradiance_texel_kernel<true> : irradiance_texel_kernel<false>, grid, dim3(256), 0, as_stream(stream), env, env_n, (uint2 *)out, n, g_irr_nphi, g_irr_ntheta, row_begin);
     }
     return launch_status("vkr_ibl_irradiance");
+}
+
+namespace vkr {
+static int irr_regions_per_side(int env_n) { return (env_n + (1 << IRR_REGION_SHIFT) - 1) >> IRR_REGION_SHIFT; }
+static int64_t irr_partial_floats(int env_n, int n_texels)
+{
+    const int per_side = irr_regions_per_side(env_n);
+    const int64_t n_groups = (n_texels + IRR_GROUP - 1) / IRR_GROUP;
+    return (int64_t)6 * per_side * per_side * 4 * n_groups * IRR_GROUP;
+}
+}  // namespace vkr
+
+extern "C" int64_t vkr_ibl_irradiance_by_region_workspace_bytes(int32_t env_n, int32_t n, int32_t row_begin, int32_t row_end)
+{
+    using namespace vkr;
+    if (env_n <= 0 || env_n > 16384 || n <= 0 || n > 4096 || row_begin < 0 || row_end < row_begin || row_end > 6 * n) {
+        fail(VKR_ERR_INVALID, "vkr_ibl_irradiance_by_region_workspace_bytes: bad sizes (env %d, cube %d, rows [%d,%d))", env_n, n, row_begin, row_end);
+        return -1;
+    }
+    return irr_partial_floats(env_n, n * (row_end - row_begin)) * 4 + 256;
+}
+
+extern "C" int32_t vkr_ibl_irradiance_by_region(const void *env, int32_t env_n, int32_t env_layout, void *out, int32_t n, int32_t row_begin, int32_t row_end,
+                                                void *workspace, int64_t workspace_bytes, void *stream)
+{
+    using namespace vkr;
+    VKR_REQUIRE(env && out && env_n > 0, "vkr_ibl_irradiance_by_region: an image is null or env size is bad");
+    VKR_REQUIRE(env_n <= 16384 && n <= 4096, "vkr_ibl_irradiance_by_region: sizes beyond 16384 (environment) or 4096 (irradiance cube): %d, %d", env_n, n);
+    int32_t rc = check_rows("vkr_ibl_irradiance_by_region", n, 6 * n, row_begin, row_end);
+    if (rc != VKR_OK) return rc;
+    if ((rc = check_env_layout("vkr_ibl_irradiance_by_region", env_n, env_layout)) != VKR_OK) return rc;
+    const bool tiled = env_layout == VKR_ENV_LAYOUT_TILED_4X4;
+    const int n_texels = n * (row_end - row_begin);
+    const int64_t floats = irr_partial_floats(env_n, n_texels), need = floats * 4 + 256;
+    VKR_REQUIRE(workspace != nullptr && workspace_bytes >= need, "vkr_ibl_irradiance_by_region: workspace of %lld bytes, %lld needed", (long long)workspace_bytes, (long long)need);
+    VKR_REQUIRE(((uintptr_t)workspace & 3u) == 0, "vkr_ibl_irradiance_by_region: workspace is not 4-byte aligned");
+    if ((rc = ensure_tables()) != VKR_OK) return rc;
+    if (n_texels == 0) return VKR_OK;
+    const int per_side = irr_regions_per_side(env_n), n_regions = 6 * per_side * per_side, n_groups = (n_texels + IRR_GROUP - 1) / IRR_GROUP;
+    const int64_t workgroups = (int64_t)((n_regions + 7) / 8) * 8 * n_groups;
+    VKR_REQUIRE(workgroups < (1ll << 31), "vkr_ibl_irradiance_by_region: too much work for one call, pass fewer rows");
+    float *partial = (float *)workspace;
+    uint32_t *uncovered = (uint32_t *)(partial + floats);
+    hipStream_t s = as_stream(stream);
+    VKR_HIP_CHECK(hipMemsetAsync(uncovered, 0, 4, s));
+    hipLaunchKernelGGL(tiled ? irradiance_region_kernel<true> : irradiance_region_kernel<false>, dim3((unsigned)workgroups), dim3(256), 0, s,
+                       env, env_n, n, g_irr_nphi, g_irr_ntheta, row_begin, n_texels, partial, per_side, n_regions, n_groups);
+    if ((rc = launch_status("vkr_ibl_irradiance_by_region")) != VKR_OK) return rc;
+    hipLaunchKernelGGL(irradiance_regions_sum_kernel, dim3((n_texels + 255) / 256), dim3(256), 0, s,
+                       partial, n_regions, n_groups, (uint2 *)out, n, g_irr_nphi, g_irr_ntheta, row_begin, n_texels, uncovered);
+    return launch_status("vkr_ibl_irradiance_by_region");
 }
 
 extern "C" int32_t vkr_ibl_prefilter(const void *env, int32_t env_n, int32_t env_layout, void *out, int32_t n, float roughness, int32_t row_begin, int32_t row_end, void *stream)

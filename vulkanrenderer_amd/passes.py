@@ -315,10 +315,37 @@ def tile_env_cube(linear: torch.Tensor) -> torch.Tensor:
 
 def irradiance(env: torch.Tensor, out: torch.Tensor, order: int = _lib.IRRADIANCE_SEQUENTIAL, rows=None,
                env_layout: int = _lib.ENV_LAYOUT_LINEAR) -> None:
+    if order == _lib.IRRADIANCE_BY_REGION:
+        irradiance_by_region(env, out, rows, env_layout)
+        return
     lib = _lib.load()
     n = out.shape[1]
     r0, r1 = _rows(6 * n, rows)
     _lib.check(lib.vkr_ibl_irradiance(_ptr(env), env.shape[1], env_layout, _ptr(out), n, order, r0, r1, _stream()))
+
+
+def irradiance_by_region(env: torch.Tensor, out: torch.Tensor, rows=None, env_layout: int = _lib.ENV_LAYOUT_LINEAR,
+                         workspace: torch.Tensor | None = None) -> torch.Tensor:
+    """The irradiance cube summed region by region of the environment (VKR_IRRADIANCE_BY_REGION).  Returns the
+    workspace (a uint8 tensor, allocated here unless given); irradiance_uncovered() reads its check word."""
+    lib = _lib.load()
+    n = out.shape[1]
+    r0, r1 = _rows(6 * n, rows)
+    need = lib.vkr_ibl_irradiance_by_region_workspace_bytes(env.shape[1], n, r0, r1)
+    if need < 0:
+        _lib.check(_lib.VKR_ERR_INVALID)
+    if workspace is None:
+        workspace = torch.empty(need, dtype=torch.uint8, device=out.device)
+    _lib.check(lib.vkr_ibl_irradiance_by_region(_ptr(env), env.shape[1], env_layout, _ptr(out), n, r0, r1,
+                                                _ptr(workspace), workspace.numel(), _stream()))
+    return workspace
+
+
+def irradiance_uncovered(workspace: torch.Tensor, need: int | None = None) -> int:
+    """Texels of the last irradiance_by_region() call on this workspace whose samples were not all found (0 when
+    the kernel is sound).  `need` = the size the call asked for, when the workspace is larger.  Synchronises."""
+    end = workspace.numel() if need is None else need
+    return int(workspace[end - 256:end - 252].cpu().view(torch.int32).item())
 
 
 def prefilter(env: torch.Tensor, out: torch.Tensor, roughness: float, rows=None,
