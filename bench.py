@@ -343,10 +343,29 @@ def time_ibl(device, reps: int = 3) -> tuple[dict, list]:
     run()
     t = np.mean([run() for _ in range(reps)], axis=0)
     eq, tile, irr_ms, pre_ms, lut_ms = t[0], t[1], t[2], t[3:8], t[8]
+
+    # the opt-in summation order that works through the environment region by region (same samples, other rounding)
+    irr_r = torch.empty_like(irr)
+    ws = P.irradiance_by_region(tiled_box[0], irr_r, env_layout=_lib.ENV_LAYOUT_TILED_4X4)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        P.irradiance_by_region(tiled_box[0], irr_r, env_layout=_lib.ENV_LAYOUT_TILED_4X4, workspace=ws)
+    e1.record()
+    torch.cuda.synchronize()
+    region_ms = e0.elapsed_time(e1) / reps
+    a, b = irr.float().cpu().numpy(), irr_r.float().cpu().numpy()
+    ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(a), 2.0 ** -14))) - 10)
+    by_region = {"irradiance_ms": round(float(region_ms), 3), "total_ms": round(float(t.sum() - irr_ms + region_ms), 3),
+                 "workspace_bytes": int(ws.numel()), "texels_with_samples_unaccounted_for": P.irradiance_uncovered(ws),
+                 "texels_that_differ_from_the_shader_order": int((P.f16_bits(irr) != P.f16_bits(irr_r)).any(-1).sum()),
+                 "of_texels": int(irr.shape[0] * irr.shape[1] * irr.shape[2]), "max_difference_binary16_ulps": round(float((np.abs(a - b) / ulp).max()), 2),
+                 "note": "VKR_IRRADIANCE_BY_REGION: bit-exact against its own restatement in oracle/, not the order the reference's shader adds in; not part of total_ms"}
     stages = {"equirect_ms": round(float(eq + tile), 3), "irradiance_ms": round(float(irr_ms), 3), "prefilter_ms": round(float(pre_ms.sum()), 3),
               "brdf_lut_ms": round(float(lut_ms), 3), "total_ms": round(float(t.sum()), 3),
               "config": "equirect 4096x2048 RGBA16F -> env 2048^2 (+ 4x4-tiled copy), irradiance 64^2 in the shader's summation order, "
-                        "prefilter 128^2 x5 mips, LUT 512^2"}
+                        "prefilter 128^2 x5 mips, LUT 512^2",
+              "irradiance_by_region": by_region}
 
     def valu(kernel, ops, ms, algorithmic, **more):
         tf = ops / (ms * 1e-3) / 1e12
@@ -385,6 +404,9 @@ def time_ibl(device, reps: int = 3) -> tuple[dict, list]:
                                               "(scratch/ubench/gather_bench, profiles/r2_gather_bench.txt); neither is read in this run"}
     except (OSError, KeyError):
         pass
+    roof.append(valu("irradiance_region_kernel (+ irradiance_regions_sum_kernel)", OPS_IRRADIANCE_SAMPLE * IRRADIANCE_SAMPLES * irr_texels, region_ms,
+                     f"{OPS_IRRADIANCE_SAMPLE} FP32 ops x {IRRADIANCE_SAMPLES} samples x {irr_texels} texels (the same sum in the by-region order; the kernel "
+                     "also looks at about 1.6 candidate cells per sample that lands elsewhere, which the figure does not count)"))
     for m in range(5):
         n = 128 >> m
         roof.append(valu(f"prefilter_texel_kernel mip {m} (roughness {m / 4:g})", OPS_PREFILTER_SAMPLE * GGX_SAMPLES * 6 * n * n, pre_ms[m],

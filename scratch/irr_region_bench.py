@@ -1,7 +1,8 @@
 """Times the by-region irradiance order against the sequential one at the bench's sizes and compares the images."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vulkanrenderer_amd import _lib, passes as P, synth
 
 dev = torch.device("cuda:0")

@@ -372,7 +372,9 @@ def test_renderer_end_frame_matches_oracle_chain(gpu, oracle):
         # IBL images computed by the library from an environment cube, then the oracle shades with the same images
         env = synth.make_env_cube(np.random.default_rng(2), 16)
         r.UploadEnvironmentCubemap(env)
-        r.CreateIrradianceCubemap()
+        for order in (_lib.IRRADIANCE_PHI_SLICES, _lib.IRRADIANCE_BY_REGION, _lib.IRRADIANCE_SEQUENTIAL):
+            r.CreateIrradianceCubemap(order)
+            assert_bits_equal(r.Read(_lib.TARGET_IRRADIANCE), oracle.irradiance(env, 8, order), f"irradiance cube, order {order}")
         r.CreatePrefilteredCubemap()
         r.CreateBRDFLUTTexture()
         f.irradiance = r.Read(_lib.TARGET_IRRADIANCE)

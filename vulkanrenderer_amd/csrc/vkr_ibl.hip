@@ -243,6 +243,75 @@ static constexpr int IRR_REGION_SHIFT = 9;   // regions of 512 x 512 texels
 static constexpr float IRR_STEP = 0.025f;    // irradiance.frag:19, sampleDelta
 static constexpr float IRR_MARGIN = 0.004f;  // radians added to a region's cone
 
+// r in the coordinates of face f: (sc, tc) as cube_face gives them on that face, and the major axis signed so that it
+// is positive on the face
+VKR_DEV f3 to_face_axes(int f, f3 r)
+{
+    switch (f) {
+    case 0: return mk3(-r.z, -r.y, r.x);
+    case 1: return mk3(r.z, -r.y, -r.x);
+    case 2: return mk3(r.x, r.z, r.y);
+    case 3: return mk3(r.x, -r.z, -r.y);
+    case 4: return mk3(r.x, -r.y, r.z);
+    default: return mk3(-r.x, -r.y, -r.z);
+    }
+}
+
+// texcube_fetch_footprint for a footprint whose face is the same for the whole wave.  A texel of the footprint that
+// lies one step outside the face is taken through edge_map: outside edge e (i = -1, i = n, j = -1, j = n), at
+// coordinate t along the edge, lies texel (m[1] + m[2] t, m[3] + m[4] t) of face m[0] -- what cube_fold gives,
+// tabulated, because a single such lane makes its whole wave walk whatever code it needs.
+template <bool TILED>
+VKR_DEV f3 fetch_footprint_on_face(const void *cube, int n, int face, int i0, int j0, float al, float be, const int (*edge_map)[5])
+{
+    // where the four texels are, then the four loads in one go, then the corner's mean
+    unsigned at[4];  // texel index within the cube (below 2^32: faces up to 16384^2)
+    bool whole = true;
+    unsigned missing = 4;
+    if (i0 >= 0 && j0 >= 0 && i0 + 1 < n && j0 + 1 < n) {  // all four on the face
+        const unsigned face0 = (unsigned)face * (unsigned)n * (unsigned)n;
+        if (!TILED) {
+            at[0] = face0 + (unsigned)j0 * (unsigned)n + (unsigned)i0; at[1] = at[0] + 1u; at[2] = at[0] + (unsigned)n; at[3] = at[2] + 1u;
+        } else {
+            const unsigned tiles4 = (unsigned)n * 4u;  // texels in one row of tiles
+            const unsigned c0 = ((unsigned)i0 >> 2) * 16u + ((unsigned)i0 & 3u), c1 = ((unsigned)(i0 + 1) >> 2) * 16u + ((unsigned)(i0 + 1) & 3u);
+            const unsigned r0 = face0 + ((unsigned)j0 >> 2) * tiles4 + ((unsigned)j0 & 3u) * 4u, r1 = face0 + ((unsigned)(j0 + 1) >> 2) * tiles4 + ((unsigned)(j0 + 1) & 3u) * 4u;
+            at[0] = r0 + c0; at[1] = r0 + c1; at[2] = r1 + c0; at[3] = r1 + c1;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = i0 + (k & 1), j = j0 + (k >> 1);
+            const bool x_out = i < 0 || i >= n, y_out = j < 0 || j >= n;
+            int f = face, ii = i, jj = j;
+            if (x_out && y_out) {  // beyond a corner of the cube: no such texel (some texel is loaded and not used)
+                missing = k; whole = false;
+                ii = i0 + 1 - (k & 1); jj = j0 + 1 - (k >> 1);
+            } else if (x_out || y_out) {
+                const int *m = edge_map[x_out ? (i < 0 ? 0 : 1) : (j < 0 ? 2 : 3)];
+                const int t = x_out ? j : i;
+                f = m[0]; ii = m[1] + m[2] * t; jj = m[3] + m[4] * t;
+            }
+            at[k] = (unsigned)cube_texel_index<TILED>(n, f, ii, jj);
+        }
+    }
+    const uint2 *base = (const uint2 *)cube;
+    rgba tx[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) tx[k] = unpack4(base[at[k]]);
+    if (!whole) {  // cube corner: the missing texel is the mean of the other three
+        float sr = 0.0f, sg = 0.0f, sb = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) if ((unsigned)k != missing) { sr += tx[k].r; sg += tx[k].g; sb += tx[k].b; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) if ((unsigned)k == missing) { tx[k].r = sr * (1.0f / 3.0f); tx[k].g = sg * (1.0f / 3.0f); tx[k].b = sb * (1.0f / 3.0f); }
+    }
+    const float w0 = (1.0f - al) * (1.0f - be), w1 = al * (1.0f - be), w2 = (1.0f - al) * be, w3 = al * be;
+    return mk3(fma_(w3, tx[3].r, fma_(w2, tx[2].r, fma_(w1, tx[1].r, w0 * tx[0].r))),
+               fma_(w3, tx[3].g, fma_(w2, tx[2].g, fma_(w1, tx[1].g, w0 * tx[0].g))),
+               fma_(w3, tx[3].b, fma_(w2, tx[2].b, fma_(w1, tx[1].b, w0 * tx[0].b))));
+}
+
 struct irr_box { int a0, na, b0, nb; };  // phi indices a0 .. a0+na-1 (mod nphi), theta indices b0 .. b0+nb-1
 
 // partial: [region][4][texels_padded] -- red, green, blue sums and the number of samples, texels_padded = n_groups * IRR_GROUP
@@ -253,18 +322,41 @@ __global__ __launch_bounds__(256) void irradiance_region_kernel(const void *env,
     __shared__ float2 phi_cs[IRR_MAX_PHI], theta_sc[IRR_MAX_THETA];
     __shared__ float frame[IRR_GROUP][9];
     __shared__ irr_box box[IRR_GROUP];
-    __shared__ uint32_t q_pk[4][IRR_QUEUE], q_b[4][IRR_QUEUE];
-    __shared__ float q_al[4][IRR_QUEUE], q_be[4][IRR_QUEUE];
+    __shared__ uint4 queue[4][IRR_QUEUE];  // base texel (+1, 16 bits each), the two weights' bits, theta index
     __shared__ float sums[4][IRR_GROUP];
+    __shared__ int edge_map[4][5];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // workgroups go to the XCDs round-robin by id: XCD x works through regions x, x + 8, ... one after the other
     const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-    const int region = (k / n_groups) * 8 + xcd, group = k % n_groups;
-    if (region >= n_regions) return;
+    const int turn = (k / n_groups) * 8 + xcd, group = k % n_groups;
+    if (turn >= n_regions) return;
+    // Regions near the middle of a face span 2.5 times the solid angle of those in its corners, and so hold as many
+    // times the samples.  With an even number of regions per side the four mirror images of a region on the six faces
+    // are 24 regions of equal weight: taken in that order, every XCD gets three of each kind.
+    int region = turn;
+    if ((regions_per_side & 1) == 0) {
+        const int half = regions_per_side >> 1, quad = turn / 24, image = turn % 24, mirror = image / 6;
+        const int qx = quad % half, qy = quad / half;
+        const int cx = (mirror & 1) ? regions_per_side - 1 - qx : qx, cy = (mirror & 2) ? regions_per_side - 1 - qy : qy;
+        region = (cy * regions_per_side + cx) * 6 + image % 6;
+    }
     const int rf = region % 6, cell = region / 6;
     const int rx = cell % regions_per_side, ry = cell / regions_per_side;
+    const uint64_t sc_later = (rf >> 1) >= 1 ? ~0ull : 0ull;  // sc is x on the y and z faces, z on the x faces
+    const uint64_t tc_later = (rf >> 1) == 2 ? ~0ull : 0ull;  // tc is y on the z faces, z or y (looked at earlier) on the others
+    const uint64_t positive = (rf & 1) == 0 ? ~0ull : 0ull;
+    const float x_lo = rx == 0 ? -INFINITY : (float)(rx << IRR_REGION_SHIFT), x_hi = rx == regions_per_side - 1 ? INFINITY : (float)((rx + 1) << IRR_REGION_SHIFT);
+    const float y_lo = ry == 0 ? -INFINITY : (float)(ry << IRR_REGION_SHIFT), y_hi = ry == regions_per_side - 1 ? INFINITY : (float)((ry + 1) << IRR_REGION_SHIFT);
     for (int t = tid; t < nphi; t += 256) phi_cs[t] = g_irr_phi_cs[t];
     if (tid < ntheta) theta_sc[tid] = g_irr_theta_sc[tid];
+    if (tid >= 64 && tid < 68) {  // the face's four neighbours, from cube_fold at t = 0 and t = 1 (it is affine in t)
+        const int e = tid - 64, off = (e & 1) ? env_n : -1;
+        int f0 = 0, i0 = 0, j0 = 0, f1 = 0, i1 = 0, j1 = 0;
+        cube_fold(env_n, rf, e < 2 ? off : 0, e < 2 ? 0 : off, f0, i0, j0);
+        if (env_n >= 2) cube_fold(env_n, rf, e < 2 ? off : 1, e < 2 ? 1 : off, f1, i1, j1);
+        else { i1 = i0; j1 = j0; }
+        edge_map[e][0] = f0; edge_map[e][1] = i0; edge_map[e][2] = i1 - i0; edge_map[e][3] = j0; edge_map[e][4] = j1 - j0;
+    }
     if (tid < IRR_GROUP) {
         const int idx = min(group * IRR_GROUP + tid, n_texels - 1);
         const int row = row_begin + idx / n, i = idx % n;
@@ -272,8 +364,11 @@ __global__ __launch_bounds__(256) void irradiance_region_kernel(const void *env,
         const f3 N = normalize3(face_dir(f, i, j, n));
         const f3 right = normalize3(mk3(N.z, 0.0f, -N.x));  // normalize(cross((0,1,0), N))
         const f3 up = normalize3(cross3(N, right));
+        // kept in the coordinates of the region's face (sc, tc, signed major axis): components swapped and negated,
+        // which commutes with the roundings of the sample direction's arithmetic
+        const f3 Nf = to_face_axes(rf, N), rightf = to_face_axes(rf, right), upf = to_face_axes(rf, up);
         float *fr = frame[tid];
-        fr[0] = N.x; fr[1] = N.y; fr[2] = N.z; fr[3] = right.x; fr[4] = right.y; fr[5] = right.z; fr[6] = up.x; fr[7] = up.y; fr[8] = up.z;
+        fr[0] = Nf.x; fr[1] = Nf.y; fr[2] = Nf.z; fr[3] = rightf.x; fr[4] = rightf.y; fr[5] = rightf.z; fr[6] = upf.x; fr[7] = upf.y; fr[8] = upf.z;
         // the region in face coordinates: base texel i0 = floor(s n - 1/2) in [x0, x1), the first and last regions
         // also take what the clamp sends them
         const float rn = 1.0f / (float)env_n;
@@ -289,10 +384,10 @@ __global__ __launch_bounds__(256) void irradiance_region_kernel(const void *env,
         const float thc = acosf(fminf(fmaxf(dot3(c, N), -1.0f), 1.0f));
         irr_box bx; bx.a0 = 0; bx.na = 0; bx.b0 = 0; bx.nb = 0;
         // N = (0, +-1, 0) has no tangent frame (right = normalize(0) is NaN, as in the shader): every sample direction
-        // is then NaN, which the lookup takes to one region; no cone can be drawn, so every region looks at all samples
+        // is then NaN, which the lookup takes to texel (0, 0) of face 1 -- region 1 -- with NaN weights
         const float frame_sum = ((right.x + right.y) + right.z) + ((up.x + up.y) + up.z);
         if (group * IRR_GROUP + tid < n_texels && !(frame_sum == frame_sum)) {
-            bx.na = nphi; bx.nb = ntheta;
+            if (region == 1) { bx.na = nphi; bx.nb = ntheta; bx.a0 = -1; }  // a0 = -1 marks it
         } else if (group * IRR_GROUP + tid < n_texels && thc - alpha < 0.5f * PI_F) {
             const float inv = 1.0f / IRR_STEP;
             bx.b0 = max(0, (int)floorf((thc - alpha) * inv) - 1);
@@ -334,7 +429,10 @@ __global__ __launch_bounds__(256) void irradiance_region_kernel(const void *env,
         float sr = 0.0f, sg = 0.0f, sb = 0.0f;
         int found = 0;
         if (na != 0) {
-            const int a0 = __builtin_amdgcn_readfirstlane(box[t].a0), b0 = __builtin_amdgcn_readfirstlane(box[t].b0), nb = __builtin_amdgcn_readfirstlane(box[t].nb);
+            int a0 = __builtin_amdgcn_readfirstlane(box[t].a0);
+            const int b0 = __builtin_amdgcn_readfirstlane(box[t].b0), nb = __builtin_amdgcn_readfirstlane(box[t].nb);
+            const uint64_t every = a0 < 0 ? ~0ull : 0ull;  // a texel without a frame: all of its samples land here
+            a0 = max(a0, 0);
             const float *fr = frame[t];
             const f3 N = mk3(fr[0], fr[1], fr[2]), right = mk3(fr[3], fr[4], fr[5]), up = mk3(fr[6], fr[7], fr[8]);
             const float inv_nb = 1.0f / (float)nb;
@@ -345,11 +443,9 @@ __global__ __launch_bounds__(256) void irradiance_region_kernel(const void *env,
             auto drain = [&](int count) {
                 if (lane < count) {
                     const int e = (q_head + lane) & (IRR_QUEUE - 1);
-                    const uint32_t pk = q_pk[w][e];
-                    cube_footprint fp;
-                    fp.face = rf; fp.i0 = (int)(pk & 0xFFFFu) - 1; fp.j0 = (int)(pk >> 16) - 1; fp.al = q_al[w][e]; fp.be = q_be[w][e];
-                    const float2 tsc = theta_sc[q_b[w][e]];
-                    const f3 c = texcube_fetch_footprint<TILED>(env, env_n, fp);
+                    const uint4 qe = queue[w][e];
+                    const float2 tsc = theta_sc[qe.w];
+                    const f3 c = fetch_footprint_on_face<TILED>(env, env_n, rf, (int)(qe.x & 0xFFFFu) - 1, (int)(qe.x >> 16) - 1, __uint_as_float(qe.y), __uint_as_float(qe.z), edge_map);
                     sr = fma_(c.x * tsc.y, tsc.x, sr);
                     sg = fma_(c.y * tsc.y, tsc.x, sg);
                     sb = fma_(c.z * tsc.y, tsc.x, sb);
@@ -365,17 +461,28 @@ __global__ __launch_bounds__(256) void irradiance_region_kernel(const void *env,
                 const float2 pcs = phi_cs[a], tsc = theta_sc[b];
                 const float st = tsc.x, ct = tsc.y;
                 const float tx = st * pcs.x, ty = st * pcs.y, tz = ct;
-                const f3 sv = mk3(fma_(tz, N.x, fma_(ty, up.x, tx * right.x)),
-                                  fma_(tz, N.y, fma_(ty, up.y, tx * right.y)),
-                                  fma_(tz, N.z, fma_(ty, up.z, tx * right.z)));
-                const cube_footprint fp = cube_linear_footprint(env_n, sv);
-                const int ic = min(max(fp.i0, 0), env_n - 1) >> IRR_REGION_SHIFT, jc = min(max(fp.j0, 0), env_n - 1) >> IRR_REGION_SHIFT;
-                const bool hit = live && fp.face == rf && ic == rx && jc == ry;
-                const uint64_t m = __ballot(hit);
+                // the direction in the face's coordinates; it lies on the face when cube_face would pick it (ties: z over y over x)
+                const float sc = fma_(tz, N.x, fma_(ty, up.x, tx * right.x));
+                const float tc = fma_(tz, N.y, fma_(ty, up.y, tx * right.y));
+                const float mj = fma_(tz, N.z, fma_(ty, up.z, tx * right.z));
+                const float asc = __builtin_fabsf(sc), atc = __builtin_fabsf(tc), ma = __builtin_fabsf(mj);
+                // the major axis wins a tie against an axis that cube_face looks at later (z, then y, then x) and loses it
+                // against one it looks at earlier; all of it as wave masks, picked by what is uniform for the workgroup
+                const uint64_t over_s = (__ballot(ma >= asc) & sc_later) | (__ballot(!(asc >= ma)) & ~sc_later);
+                const uint64_t over_t = (__ballot(ma >= atc) & tc_later) | (__ballot(!(atc >= ma)) & ~tc_later);
+                const uint64_t side = (__ballot(mj >= 0.0f) & positive) | (__ballot(!(mj <= 0.0f)) & ~positive);
+                const float ima = rcp_rn_checked(ma);
+                const float s = fma_(sc * ima, 0.5f, 0.5f), tt = fma_(tc * ima, 0.5f, 0.5f);
+                const float x = s * (float)env_n - 0.5f, y = tt * (float)env_n - 0.5f;
+                // floor(x) clamped to the face lies in the region's columns [x0, x1) when x0 <= x < x1, the first and the
+                // last region being open towards the clamp
+                const uint64_t inside = __ballot(x >= x_lo) & __ballot(x < x_hi) & __ballot(y >= y_lo) & __ballot(y < y_hi);
+                const uint64_t m = __ballot(live) & ((over_s & over_t & side & inside) | every);
+                const bool hit = (m >> lane) & 1ull;
                 if (hit) {
                     const int e = (q_head + q_count + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))) & (IRR_QUEUE - 1);
-                    q_pk[w][e] = (uint32_t)(fp.i0 + 1) | ((uint32_t)(fp.j0 + 1) << 16);
-                    q_al[w][e] = fp.al; q_be[w][e] = fp.be; q_b[w][e] = (uint32_t)b;
+                    const float fx = __builtin_floorf(x), fy = __builtin_floorf(y);
+                    queue[w][e] = make_uint4((uint32_t)((int)fx + 1) | ((uint32_t)((int)fy + 1) << 16), __float_as_uint(x - fx), __float_as_uint(y - fy), (uint32_t)b);
                 }
                 const int hits = __popcll(m);
                 q_count += hits; found += hits;

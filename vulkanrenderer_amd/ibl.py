@@ -26,6 +26,7 @@ class IblConfig:
     prefilter_res: int = 128    # VulkanRenderer.cs:815
     prefilter_mips: int = 5     # roughness = mip / (mips - 1), VulkanRenderer.cs:874
     lut_res: int = 512          # VulkanRenderer.cs:966
+    irradiance_order: int = _lib.IRRADIANCE_SEQUENTIAL   # the shader's own order; IRRADIANCE_BY_REGION is faster, other rounding
 
 
 def row_share(total_rows: int, rank: int, world: int) -> tuple[int, int, int]:
@@ -57,8 +58,8 @@ class HipIblBackend:
             return self.P.tile_env_cube(env), _lib.ENV_LAYOUT_TILED_4X4
         return env, _lib.ENV_LAYOUT_LINEAR
 
-    def irradiance(self, env, out, rows, env_layout=_lib.ENV_LAYOUT_LINEAR):
-        self.P.irradiance(env, out, _lib.IRRADIANCE_SEQUENTIAL, rows=rows, env_layout=env_layout)
+    def irradiance(self, env, out, rows, env_layout=_lib.ENV_LAYOUT_LINEAR, order=_lib.IRRADIANCE_SEQUENTIAL):
+        self.P.irradiance(env, out, order, rows=rows, env_layout=env_layout)
 
     def prefilter(self, env, out, roughness, rows, env_layout=_lib.ENV_LAYOUT_LINEAR):
         self.P.prefilter(env, out, roughness, rows=rows, env_layout=env_layout)
@@ -102,7 +103,10 @@ class IblPrecompute:
         n = cfg.irradiance_res
         irr_flat, irr = self._padded_cube(n)
         r0, r1, per = row_share(6 * n, self.rank, self.world)
-        be.irradiance(sampled, irr, (r0, r1), layout)
+        if cfg.irradiance_order == _lib.IRRADIANCE_SEQUENTIAL:
+            be.irradiance(sampled, irr, (r0, r1), layout)
+        else:
+            be.irradiance(sampled, irr, (r0, r1), layout, order=cfg.irradiance_order)
         self._all_gather_rows(irr_flat, per)
 
         mips = []
