@@ -100,7 +100,7 @@ typedef struct VkrLightInfo {
                                        starts in (regions numbered (row * per_side + column) * 6 + face); within a
                                        region the k-th sample in the shader's order goes to accumulator k mod 64, the
                                        64 accumulators are combined pairwise (partner = index xor 32, 16, .. 1) and the
-                                       region sums added in region order.  About twice as fast at 2048^2 faces (the
+                                       region sums added in region order.  Nearly three times as fast at 2048^2 faces (the
                                        lookups hit the cache); differs from the shader's order in rounding only */
 
 VKR_EXPORT const char *vkr_last_error(void);
@@ -314,7 +314,8 @@ VKR_EXPORT int32_t vkr_tile_rgba16f_faces(const void *linear, void *tiled, int32
 /* Replaces CreateIrradianceCubemap's six draws (VulkanRenderer.cs:734-813). */
 VKR_EXPORT int32_t vkr_ibl_irradiance(const void *env, int32_t env_n, int32_t env_layout, void *out, int32_t n, int32_t order,
                            int32_t row_begin, int32_t row_end, void *stream);
-/* The same six draws summed in the VKR_IRRADIANCE_BY_REGION order.  `workspace` is device memory of at least
+/* The same six draws summed in the VKR_IRRADIANCE_BY_REGION order (environment faces up to 8192^2, irradiance faces up to
+ * 4096^2).  `workspace` is device memory of at least
  * vkr_ibl_irradiance_by_region_workspace_bytes(env_n, n, row_begin, row_end) bytes (-1: bad sizes), 4-byte aligned,
  * used until the work on `stream` has finished; the call itself allocates nothing.  The 32-bit word 256 bytes
  * before the end of that size then holds the number of texels whose 15 876 samples were not all found: 0, unless

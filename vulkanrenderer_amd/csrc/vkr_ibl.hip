@@ -264,18 +264,20 @@ VKR_DEV f3 to_face_axes(int f, f3 r)
 template <bool TILED>
 VKR_DEV f3 fetch_footprint_on_face(const void *cube, int n, int face, int i0, int j0, float al, float be, const int (*edge_map)[5])
 {
-    // where the four texels are, then the four loads in one go, then the corner's mean
-    unsigned at[4];  // texel index within the cube (below 2^32: faces up to 16384^2)
+    // where the four texels are (byte offsets; the caller keeps cubes below 4 GiB), then the four loads in one go, then
+    // the corner's mean.  Products of small factors as 24-bit multiplies: the 32-bit one issues at a quarter of the rate.
+    unsigned at[4];
     bool whole = true;
     unsigned missing = 4;
     if (i0 >= 0 && j0 >= 0 && i0 + 1 < n && j0 + 1 < n) {  // all four on the face
-        const unsigned face0 = (unsigned)face * (unsigned)n * (unsigned)n;
+        const unsigned face0 = (unsigned)face * (unsigned)n * (unsigned)n * 8u;
         if (!TILED) {
-            at[0] = face0 + (unsigned)j0 * (unsigned)n + (unsigned)i0; at[1] = at[0] + 1u; at[2] = at[0] + (unsigned)n; at[3] = at[2] + 1u;
+            at[0] = face0 + (__umul24((unsigned)j0, (unsigned)n) + (unsigned)i0) * 8u; at[1] = at[0] + 8u; at[2] = at[0] + (unsigned)n * 8u; at[3] = at[2] + 8u;
         } else {
-            const unsigned tiles4 = (unsigned)n * 4u;  // texels in one row of tiles
-            const unsigned c0 = ((unsigned)i0 >> 2) * 16u + ((unsigned)i0 & 3u), c1 = ((unsigned)(i0 + 1) >> 2) * 16u + ((unsigned)(i0 + 1) & 3u);
-            const unsigned r0 = face0 + ((unsigned)j0 >> 2) * tiles4 + ((unsigned)j0 & 3u) * 4u, r1 = face0 + ((unsigned)(j0 + 1) >> 2) * tiles4 + ((unsigned)(j0 + 1) & 3u) * 4u;
+            const unsigned tile_row = (unsigned)n * 32u;  // bytes in one row of tiles
+            const unsigned c0 = ((unsigned)i0 >> 2) * 128u + ((unsigned)i0 & 3u) * 8u, c1 = ((unsigned)(i0 + 1) >> 2) * 128u + ((unsigned)(i0 + 1) & 3u) * 8u;
+            const unsigned r0 = face0 + __umul24((unsigned)j0 >> 2, tile_row) + ((unsigned)j0 & 3u) * 32u;
+            const unsigned r1 = face0 + __umul24((unsigned)(j0 + 1) >> 2, tile_row) + ((unsigned)(j0 + 1) & 3u) * 32u;
             at[0] = r0 + c0; at[1] = r0 + c1; at[2] = r1 + c0; at[3] = r1 + c1;
         }
     } else {
@@ -292,13 +294,13 @@ VKR_DEV f3 fetch_footprint_on_face(const void *cube, int n, int face, int i0, in
                 const int t = x_out ? j : i;
                 f = m[0]; ii = m[1] + m[2] * t; jj = m[3] + m[4] * t;
             }
-            at[k] = (unsigned)cube_texel_index<TILED>(n, f, ii, jj);
+            at[k] = (unsigned)cube_texel_index<TILED>(n, f, ii, jj) * 8u;
         }
     }
-    const uint2 *base = (const uint2 *)cube;
+    const char *base = (const char *)cube;
     rgba tx[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) tx[k] = unpack4(base[at[k]]);
+    for (int k = 0; k < 4; k++) tx[k] = unpack4(*(const uint2 *)(base + at[k]));
     if (!whole) {  // cube corner: the missing texel is the mean of the other three
         float sr = 0.0f, sg = 0.0f, sb = 0.0f;
 #pragma unroll
@@ -451,13 +453,18 @@ __global__ __launch_bounds__(256) void irradiance_region_kernel(const void *env,
                     sb = fma_(c.z * tsc.y, tsc.x, sb);
                 }
             };
+            // cell kk = base + lane is row q = kk / nb of the box, column kk - q nb; both advance by 64 cells a step without
+            // a division.  lane / nb: (lane + 1/2) / nb is at least 1/(2 nb) >= 0.0079 from an integer, the product's error
+            // is below 0.002
+            const int step_q = (int)(64.5f * inv_nb), step_c = 64 - step_q * nb;
+            int q = (int)(((float)lane + 0.5f) * inv_nb), col = lane - q * nb;
             for (int base = 0; base < cells; base += 64) {
-                const bool live = base + lane < cells;
-                const int kk = min(base + lane, cells - 1);
-                // kk / nb: (kk + 1/2) / nb is at least 1/(2 nb) >= 0.0079 from an integer, the product's error is below 0.002
-                const int q = (int)(((float)kk + 0.5f) * inv_nb);
-                const int b = b0 + (kk - q * nb);
-                const int a = q < wrapped ? q : a0 + (q - wrapped);
+                const bool live = q < na;  // rows past the box: the cell is evaluated like the last row's and not counted
+                const int qq = min(q, na - 1);
+                const int b = b0 + col;
+                const int a = qq < wrapped ? qq : a0 + (qq - wrapped);
+                q += step_q; col += step_c;
+                if (col >= nb) { col -= nb; q++; }
                 const float2 pcs = phi_cs[a], tsc = theta_sc[b];
                 const float st = tsc.x, ct = tsc.y;
                 const float tx = st * pcs.x, ty = st * pcs.y, tz = ct;
@@ -784,7 +791,7 @@ static int64_t irr_partial_floats(int env_n, int n_texels)
 extern "C" int64_t vkr_ibl_irradiance_by_region_workspace_bytes(int32_t env_n, int32_t n, int32_t row_begin, int32_t row_end)
 {
     using namespace vkr;
-    if (env_n <= 0 || env_n > 16384 || n <= 0 || n > 4096 || row_begin < 0 || row_end < row_begin || row_end > 6 * n) {
+    if (env_n <= 0 || env_n > 8192 || n <= 0 || n > 4096 || row_begin < 0 || row_end < row_begin || row_end > 6 * n) {
         fail(VKR_ERR_INVALID, "vkr_ibl_irradiance_by_region_workspace_bytes: bad sizes (env %d, cube %d, rows [%d,%d))", env_n, n, row_begin, row_end);
         return -1;
     }
@@ -796,7 +803,7 @@ extern "C" int32_t vkr_ibl_irradiance_by_region(const void *env, int32_t env_n, 
 {
     using namespace vkr;
     VKR_REQUIRE(env && out && env_n > 0, "vkr_ibl_irradiance_by_region: an image is null or env size is bad");
-    VKR_REQUIRE(env_n <= 16384 && n <= 4096, "vkr_ibl_irradiance_by_region: sizes beyond 16384 (environment) or 4096 (irradiance cube): %d, %d", env_n, n);
+    VKR_REQUIRE(env_n <= 8192 && n <= 4096, "vkr_ibl_irradiance_by_region: sizes beyond 8192 (environment: the kernel addresses the cube with 32-bit byte offsets) or 4096 (irradiance cube): %d, %d", env_n, n);
     int32_t rc = check_rows("vkr_ibl_irradiance_by_region", n, 6 * n, row_begin, row_end);
     if (rc != VKR_OK) return rc;
     if ((rc = check_env_layout("vkr_ibl_irradiance_by_region", env_n, env_layout)) != VKR_OK) return rc;
