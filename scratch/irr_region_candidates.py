@@ -117,6 +117,25 @@ for trial in range(60):
         else:
             na = nphi
         tot["cone_box"] += na * (b1 - b0 + 1)
+        # the same box, but phi from the azimuths of the region's corners when N lies outside the region, and theta's upper
+        # end from the farthest corner
+        fNn, sNn, tNn = cube_face_st(Nv[None, :])
+        slack = 2.0 / ENV
+        n_in = fNn[0] == rf and u0 - slack <= 2 * sNn[0] - 1 <= u1 + slack and v0 - slack <= 2 * tNn[0] - 1 <= v1 + slack
+        cz = np.array([k @ Nv / np.linalg.norm(k) for k in corners]); cth = np.arccos(np.clip(cz, -1, 1))
+        b1c = min(b1, int(np.floor((cth.max() + 0.004) / step)) + 1)
+        na2 = na
+        if not n_in:
+            phc0 = np.arctan2(c @ up, c @ right)
+            d = np.array([np.arctan2(k @ up, k @ right) for k in corners]) - phc0
+            d = (d + np.pi) % (2 * np.pi) - np.pi
+            na2 = min(na, int(np.floor((d.max() - d.min() + 0.008) / step)) + 4)
+        tot["corner_box"] = tot.get("corner_box", 0) + na2 * (b1c - b0 + 1)
+        if na == nphi:
+            tot["full_pairs"] = tot.get("full_pairs", 0) + 1
+            tot["full_pairs_inside"] = tot.get("full_pairs_inside", 0) + int(n_in)
+            tot["full_cells"] = tot.get("full_cells", 0) + na * (b1 - b0 + 1)
+            tot["full_cells_corner"] = tot.get("full_cells_corner", 0) + na2 * (b1c - b0 + 1)
         tot["hits"] += int(hit.sum())
         # bounding box of the true hit set + 1 index margin each side (what an ideal shape box would give)
         if hit.any():

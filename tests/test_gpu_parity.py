@@ -321,6 +321,27 @@ def test_irradiance_by_region_of_a_large_environment(gpu, oracle):
         assert (part.view(6 * n, n, 4)[:r0] == 7.0).all() and (part.view(6 * n, n, 4)[r1:] == 7.0).all()
         with pytest.raises(_lib.VkrError):
             P.irradiance_by_region(dev_env, out, env_layout=layout, workspace=ws[:need - 1])
+    # more shapes of regions and texel grids, against the kernel in the shader's order: every sample accounted for, and
+    # the two sums within rounding of each other (three regions per side, eight per side, one; odd and even cubes)
+    for env_n, n in ((1536, 8), (4096, 6), (512, 16), (2048, 9), (72, 5)):
+        gen = torch.Generator(device=gpu).manual_seed(env_n)
+        dev_env = (torch.rand((6, env_n, env_n, 4), generator=gen, device=gpu) * 4.0).to(torch.float16)  # made on the device: 4096^2 faces are 0.8 GB
+        layout = _lib.ENV_LAYOUT_LINEAR
+        if env_n % 8 == 0:
+            dev_env, layout = P.tile_env_cube(dev_env), _lib.ENV_LAYOUT_TILED_4X4
+        out = torch.zeros((6, n, n, 4), dtype=torch.float16, device=gpu)
+        seq = torch.zeros_like(out)
+        ws = P.irradiance_by_region(dev_env, out, env_layout=layout)
+        P.irradiance(dev_env, seq, 0, env_layout=layout)
+        assert P.irradiance_uncovered(ws) == 0, (env_n, n)
+        a, b = seq.float().cpu().numpy(), out.float().cpu().numpy()
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        assert (np.isnan(a) | (np.abs(a - b) <= 1.0 * f16_ulp(a))).all(), (env_n, n)
+        del dev_env, ws
+    env_n, n = 1024, 3
+    env = synth.make_env_cube(np.random.default_rng(env_n + n), env_n)
+    dev_env, layout = P.to_device_f16(env, gpu), _lib.ENV_LAYOUT_LINEAR
+    out = torch.zeros((6, n, n, 4), dtype=torch.float16, device=gpu)
     with pytest.raises(_lib.VkrError):
         _lib.check(lib.vkr_ibl_irradiance(P._ptr(dev_env), env_n, layout, P._ptr(out), n, 2, 0, 6 * n, None))
     assert lib.vkr_ibl_irradiance_by_region_workspace_bytes(0, 4, 0, 24) == -1

@@ -230,18 +230,17 @@ __global__ __launch_bounds__(256) void irradiance_slices_kernel(const void *env,
 // combined pairwise with the partners 32, 16, 8, 4, 2, 1 lanes away.  irradiance_regions_sum_kernel then adds a
 // texel's region sums in region order.  The result differs from the single running sum in rounding only.
 //
-// Which samples of texel N land in a region: in N's tangent frame the region lies inside a cone (centre c, half
-// angle alpha) at polar angle acos(c.N) and azimuth atan2(c.up, c.right); samples outside the index box that
-// cone spans (plus a margin of one index and 0.004 rad) cannot land in it.  Every cell of the box is then decided
-// exactly: the sample's direction and footprint are computed with the arithmetic of the other kernels, and the
-// sample belongs to the region that holds the footprint's base texel (clamped to the face).  A sample has one such
-// region, so it is counted exactly once; the count of samples found travels with the sums, and a texel whose
-// count is not nphi * ntheta is reported.
+// Which samples of texel N land in a region: in N's tangent frame the region spans a range of polar angles and a
+// range of azimuths, found from its corners and edges; samples outside that box of (phi, theta) indices (widened by
+// 0.004 rad) cannot land in it.  Every cell of the box is then decided exactly: the sample's direction and footprint
+// are computed with the arithmetic of the other kernels, and the sample belongs to the region that holds the
+// footprint's base texel (clamped to the face).  A sample has one such region, so it is counted exactly once; the
+// count of samples found travels with the sums, and a texel whose count is not nphi * ntheta is reported.
 static constexpr int IRR_GROUP = 64;         // output texels per workgroup
 static constexpr int IRR_QUEUE = 128;        // entries of a wave's queue of samples to fetch (a ring; at most 63 + 64 are held)
 static constexpr int IRR_REGION_SHIFT = 9;   // regions of 512 x 512 texels
 static constexpr float IRR_STEP = 0.025f;    // irradiance.frag:19, sampleDelta
-static constexpr float IRR_MARGIN = 0.004f;  // radians added to a region's cone
+static constexpr float IRR_MARGIN = 0.004f;  // radians by which a region's bounds are widened
 
 // r in the coordinates of face f: (sc, tc) as cube_face gives them on that face, and the major axis signed so that it
 // is positive on the face
@@ -377,45 +376,70 @@ __global__ __launch_bounds__(256) void irradiance_region_kernel(const void *env,
         const int x0 = rx << IRR_REGION_SHIFT, x1 = min((rx + 1) << IRR_REGION_SHIFT, env_n), y0 = ry << IRR_REGION_SHIFT, y1 = min((ry + 1) << IRR_REGION_SHIFT, env_n);
         const float u0 = x0 == 0 ? -1.0f : (float)(2 * x0 + 1) * rn - 1.0f, u1 = x1 == env_n ? 1.0f : (float)(2 * x1 + 1) * rn - 1.0f;
         const float v0 = y0 == 0 ? -1.0f : (float)(2 * y0 + 1) * rn - 1.0f, v1 = y1 == env_n ? 1.0f : (float)(2 * y1 + 1) * rn - 1.0f;
-        const f3 c = normalize3(face_point(rf, 0.5f * (u0 + u1), 0.5f * (v0 + v1)));
-        float cosa = dot3(c, normalize3(face_point(rf, u0, v0)));
-        cosa = fminf(cosa, dot3(c, normalize3(face_point(rf, u1, v0))));
-        cosa = fminf(cosa, dot3(c, normalize3(face_point(rf, u0, v1))));
-        cosa = fminf(cosa, dot3(c, normalize3(face_point(rf, u1, v1))));
-        const float alpha = acosf(fminf(cosa, 1.0f)) + IRR_MARGIN;
-        const float thc = acosf(fminf(fmaxf(dot3(c, N), -1.0f), 1.0f));
+        // The region as seen from N, in the coordinates of its face (where N, right, up are Nf, rightf, upf and the region is
+        // the pyramid over [u0, u1] x [v0, v1] at height 1; its edges are arcs of great circles).  Polar angle: the
+        // farthest point is a corner, the nearest lies on an edge or is N itself.  Azimuth: if N lies outside, the region
+        // spans less than half a turn, between the azimuths of two of its corners.  Each bound is widened by IRR_MARGIN,
+        // far above the rounding in here and in the running sums that give phi and theta (below 1e-4).
+        const float us[4] = {u0, u1, u0, u1}, vs[4] = {v0, v0, v1, v1};
+        f3 corner[4];
+        float th_max = 0.0f, th_corner[4];
+        const f3 centre = mk3(0.5f * (u0 + u1), 0.5f * (v0 + v1), 1.0f);
+        const float phc = atan2f(dot3(centre, upf), dot3(centre, rightf));
+        float d_lo = 0.0f, d_hi = 0.0f;  // azimuth relative to the centre's
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            corner[k] = normalize3(mk3(us[k], vs[k], 1.0f));
+            th_corner[k] = acosf(fminf(fmaxf(dot3(corner[k], Nf), -1.0f), 1.0f));
+            th_max = fmaxf(th_max, th_corner[k]);
+            float d = atan2f(dot3(corner[k], upf), dot3(corner[k], rightf)) - phc;
+            d = d > PI_F ? d - 2.0f * PI_F : (d <= -PI_F ? d + 2.0f * PI_F : d);
+            d_lo = fminf(d_lo, d); d_hi = fmaxf(d_hi, d);
+        }
+        const float slack = 4.0f * rn;  // two texels
+        const bool n_inside = Nf.z > 0.0f && Nf.x >= (u0 - slack) * Nf.z && Nf.x <= (u1 + slack) * Nf.z && Nf.y >= (v0 - slack) * Nf.z && Nf.y <= (v1 + slack) * Nf.z;
+        float th_min = 0.0f;
+        if (!n_inside) {
+            th_min = 4.0f;
+            const int ea[4] = {0, 1, 3, 2}, eb[4] = {1, 3, 2, 0};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const f3 A = corner[ea[e]], B = corner[eb[e]];
+                const f3 nrm = normalize3(cross3(A, B));
+                // the foot of the perpendicular from N lies on the arc when N is on the inner side of both end planes
+                const bool on_arc = dot3(cross3(A, Nf), nrm) >= 0.0f && dot3(cross3(Nf, B), nrm) >= 0.0f;
+                const float d = on_arc ? asinf(fminf(__builtin_fabsf(dot3(Nf, nrm)), 1.0f)) : fminf(th_corner[ea[e]], th_corner[eb[e]]);
+                th_min = fminf(th_min, d);
+            }
+        }
         irr_box bx; bx.a0 = 0; bx.na = 0; bx.b0 = 0; bx.nb = 0;
         // N = (0, +-1, 0) has no tangent frame (right = normalize(0) is NaN, as in the shader): every sample direction
         // is then NaN, which the lookup takes to texel (0, 0) of face 1 -- region 1 -- with NaN weights
         const float frame_sum = ((right.x + right.y) + right.z) + ((up.x + up.y) + up.z);
+        const float inv = 1.0f / IRR_STEP;
         if (group * IRR_GROUP + tid < n_texels && !(frame_sum == frame_sum)) {
             if (region == 1) { bx.na = nphi; bx.nb = ntheta; bx.a0 = -1; }  // a0 = -1 marks it
-        } else if (group * IRR_GROUP + tid < n_texels && thc - alpha < 0.5f * PI_F) {
-            const float inv = 1.0f / IRR_STEP;
-            bx.b0 = max(0, (int)floorf((thc - alpha) * inv) - 1);
-            bx.nb = min(ntheta - 1, (int)floorf((thc + alpha) * inv) + 1) - bx.b0 + 1;
-            const float sa = sinf(alpha), sth = sinf(thc);
-            bool full = thc <= alpha || sa >= 0.999f * sth;
-            int alo = 0, ahi = 0;
-            float lo = 0.0f, hi = 0.0f;
+        } else if (group * IRR_GROUP + tid < n_texels && (th_min - IRR_MARGIN) * inv < (float)ntheta) {
+            bx.b0 = max(0, (int)ceilf((th_min - IRR_MARGIN) * inv));
+            bx.nb = min(ntheta - 1, (int)floorf((th_max + IRR_MARGIN) * inv)) - bx.b0 + 1;
+            // IRR_MARGIN of arc is this much azimuth at the polar angle where the region comes nearest to N
+            const float margin = IRR_MARGIN / fmaxf(sinf(th_min), 1e-6f);
+            bool full = n_inside || (d_hi - d_lo) + 2.0f * margin >= 2.0f * PI_F - 2.0f * IRR_STEP;
             if (!full) {
-                const float dphi = asinf(fminf(sa / sth, 1.0f)) + IRR_MARGIN;
-                float phc = atan2f(dot3(c, up), dot3(c, right));
-                if (phc < 0.0f) phc += 2.0f * PI_F;
-                lo = phc - dphi; hi = phc + dphi;
-                alo = (int)floorf(lo * inv) - 1; ahi = (int)floorf(hi * inv) + 1;
-                full = ahi - alo + 1 >= nphi;
-            }
-            if (!full) {
-                if (alo < 0) {  // phi in [lo + 2 pi, 2 pi) and in [0, hi]
-                    const int w0 = min((int)floorf((lo + 2.0f * PI_F) * inv) - 1, nphi);
+                const float centre_phi = phc < 0.0f ? phc + 2.0f * PI_F : phc;
+                const float lo = centre_phi + d_lo - margin, hi = centre_phi + d_hi + margin;
+                // phi index 0 also stands for the angle 2 pi, index nphi - 1 for just below it
+                const int alo = (int)ceilf(lo * inv), ahi = (int)floorf(hi * inv);
+                if (lo < 0.0f && hi >= 2.0f * PI_F) full = true;
+                else if (lo < 0.0f) {  // phi in [lo + 2 pi, 2 pi) and in [0, hi]
+                    const int w0 = min((int)ceilf((lo + 2.0f * PI_F) * inv), nphi);
                     if (w0 <= ahi + 1) full = true;
                     else { bx.a0 = w0; bx.na = (nphi - w0) + (ahi + 1); }
-                } else if (ahi >= nphi) {  // phi in [lo, 2 pi) and in [0, hi - 2 pi]
-                    const int e = max((int)floorf((hi - 2.0f * PI_F) * inv) + 1, -1);
-                    if (e >= alo - 1) full = true;
-                    else { bx.a0 = alo; bx.na = (nphi - alo) + (e + 1); }
-                } else { bx.a0 = alo; bx.na = ahi - alo + 1; }
+                } else if (hi >= 2.0f * PI_F) {  // phi in [lo, 2 pi) and in [0, hi - 2 pi]
+                    const int e = (int)floorf((hi - 2.0f * PI_F) * inv), first = min(alo, nphi);
+                    if (e >= first - 1) full = true;
+                    else { bx.a0 = first; bx.na = (nphi - first) + (e + 1); }
+                } else { bx.a0 = alo; bx.na = max(min(ahi, nphi - 1) - alo + 1, 0); }
             }
             if (full || bx.na >= nphi) { bx.a0 = 0; bx.na = nphi; }
             if (bx.nb <= 0) bx.na = 0;
