@@ -426,21 +426,25 @@ def time_ibl_sharded(rank: int, world: int, device, reps: int = 3) -> dict:
     import torch.distributed as dist
     from vulkanrenderer_amd import _lib, passes as P, synth
     from vulkanrenderer_amd.ibl import IblConfig, IblPrecompute
-    cfg = IblConfig(env_res=2048, irradiance_res=64, prefilter_res=128, prefilter_mips=5, lut_res=512)
     src = P.to_device_f16(synth.make_equirect(np.random.default_rng(SEED + 77), 4096, 2048, hdr=True), device)
-    pre = IblPrecompute(cfg, rank, world, device=device)
-    pre.run(src, _lib.SRC_RGBA16F)
-    torch.cuda.synchronize(); dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        res = pre.run(src, _lib.SRC_RGBA16F)
-    torch.cuda.synchronize()
-    t = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    del res
-    return {"ms": round(float(t.item()), 3), "world": world,
+
+    def timed(order):
+        cfg = IblConfig(env_res=2048, irradiance_res=64, prefilter_res=128, prefilter_mips=5, lut_res=512, irradiance_order=order)
+        pre = IblPrecompute(cfg, rank, world, device=device)
+        pre.run(src, _lib.SRC_RGBA16F)
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            res = pre.run(src, _lib.SRC_RGBA16F)
+        torch.cuda.synchronize()
+        t = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        del res
+        return round(float(t.item()), 3)
+
+    return {"ms": timed(_lib.IRRADIANCE_SEQUENTIAL), "ms_with_irradiance_by_region": timed(_lib.IRRADIANCE_BY_REGION), "world": world,
             "config": "equirect 4096x2048 -> env 2048^2 on every rank; rows of irradiance 64^2, prefilter 128^2 x5 mips and LUT 512^2 split "
-                      "over the ranks and all-gathered"}
+                      "over the ranks and all-gathered; ms: the irradiance pass in the shader's summation order"}
 
 
 def time_coverage(f, dev_frame, renderer, device) -> dict:

@@ -210,7 +210,7 @@ def test_hip_strips_render_from_draw_calls(gpu, oracle, tmp_path):
     assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
 
 
-def _ibl_worker(rank, world, port, out_path):
+def _ibl_worker(rank, world, port, out_path, order):
     import torch
     import torch.distributed as dist
     from vulkanrenderer_amd import _lib, passes as P
@@ -220,7 +220,7 @@ def _ibl_worker(rank, world, port, out_path):
     try:
         dev = torch.device("cuda", 0)
         src = P.to_device_f16(synth.make_equirect(np.random.default_rng(17), 64, 32, hdr=True), dev)
-        res = IblPrecompute(IblConfig(env_res=32, irradiance_res=5, prefilter_res=12, prefilter_mips=3, lut_res=21), rank, world, device=dev).run(src, _lib.SRC_RGBA16F)
+        res = IblPrecompute(IblConfig(env_res=32, irradiance_res=5, prefilter_res=12, prefilter_mips=3, lut_res=21, irradiance_order=order), rank, world, device=dev).run(src, _lib.SRC_RGBA16F)
         torch.cuda.synchronize()
         np.savez(out_path + f".{rank}.npz", irradiance=P.f16_bits(res["irradiance"]), brdf_lut=P.f16_bits(res["brdf_lut"]),
                  **{f"prefilter{m}": P.f16_bits(t) for m, t in enumerate(res["prefilter"])})
@@ -228,19 +228,20 @@ def _ibl_worker(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_hip_ibl_shards_over_gloo_equal_single_rank(gpu, world, tmp_path):
+@pytest.mark.parametrize("world,order", [(2, 0), (3, 0), (3, 2)])
+def test_hip_ibl_shards_over_gloo_equal_single_rank(gpu, world, order, tmp_path):
     """The IBL precompute with its rows split over ranks that share cuda:0 (HIP kernels, all-gather over gloo): every
-    rank ends up with the images one rank computes alone, bit for bit; sizes that do not divide by the world size."""
+    rank ends up with the images one rank computes alone, bit for bit; sizes that do not divide by the world size.
+    order: the irradiance pass in the shader's summation order (0) or by region of the environment (2)."""
     import torch
     import torch.multiprocessing as mp
     from vulkanrenderer_amd import _lib, passes as P
     from vulkanrenderer_amd.ibl import IblConfig, IblPrecompute
     src = P.to_device_f16(synth.make_equirect(np.random.default_rng(17), 64, 32, hdr=True), gpu)
-    alone = IblPrecompute(IblConfig(env_res=32, irradiance_res=5, prefilter_res=12, prefilter_mips=3, lut_res=21), 0, 1, device=gpu).run(src, _lib.SRC_RGBA16F)
+    alone = IblPrecompute(IblConfig(env_res=32, irradiance_res=5, prefilter_res=12, prefilter_mips=3, lut_res=21, irradiance_order=order), 0, 1, device=gpu).run(src, _lib.SRC_RGBA16F)
     torch.cuda.synchronize()
     out_path = str(tmp_path / "ibl")
-    mp.spawn(_ibl_worker, args=(world, _free_port(), out_path), nprocs=world, join=True)
+    mp.spawn(_ibl_worker, args=(world, _free_port(), out_path, order), nprocs=world, join=True)
     for rank in range(world):
         got = np.load(out_path + f".{rank}.npz")
         assert np.array_equal(got["irradiance"], P.f16_bits(alone["irradiance"])), rank
