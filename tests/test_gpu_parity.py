@@ -572,8 +572,7 @@ def test_cpp_host_program_matches_oracle(gpu, oracle, tmp_path, mode):
     submission, instead of EndFrame."""
     import os
     import subprocess
-    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "renderer_roundtrip")
-    assert os.path.exists(exe), "tests/cpp/renderer_roundtrip is not built: run __graft_entry__.build()"
+    exe = _cpp_host()
     w, h, nl, dres, cres, eres, ires, pres, lres = 104, 56, 3, 64, 16, 16, 4, 8, 16
     f = synth.make_frame(52, w, h, nl, cres, dres, irr_res=ires, pref_res=pres, lut_res=lres)
     env = synth.make_env_cube(np.random.default_rng(8), eres)
@@ -687,6 +686,15 @@ def test_tiled_environment_cube(gpu, oracle):
         P.tile_env_cube(odd)
     with pytest.raises(_lib.VkrError):
         P.irradiance(odd, irr, 0, env_layout=T)
+
+
+def _cpp_host() -> str:
+    """The C++ host program: tests/cpp/renderer_roundtrip, or the build VKR_TEST_CPP_HOST names (scratch/asan/build.sh makes
+    one whose host code, the library's included, runs under the address and undefined-behaviour sanitizers)."""
+    import os
+    exe = os.environ.get("VKR_TEST_CPP_HOST") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "renderer_roundtrip")
+    assert os.path.exists(exe), f"{exe} is not built: run __graft_entry__.build()"
+    return exe
 
 
 def _camera_scene(cam, target=(0.0, 0.0, 0.0), aspect=16.0 / 9.0):
@@ -1278,8 +1286,7 @@ def test_cpp_host_program_renders_from_draw_calls(gpu, oracle, tmp_path, mode):
     bloom 1, bloom 2, post-process) and submitted once, as VulkanRenderer.EndFrame is written."""
     import os
     import subprocess
-    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "renderer_roundtrip")
-    assert os.path.exists(exe), "tests/cpp/renderer_roundtrip is not built: run __graft_entry__.build()"
+    exe = _cpp_host()
     w, h, nl, dres, cres, eres, ires, pres, lres = 120, 64, 2, 64, 16, 16, 4, 8, 16
     f = synth.make_frame(53, w, h, nl, cres, dres, irr_res=ires, pref_res=pres, lut_res=lres)
     f.scene = _camera_scene((2.0, 1.6, -4.0), aspect=w / h)
