@@ -65,6 +65,21 @@ __global__ __launch_bounds__(256) void rate_kernel(float *out, float a, float b)
             if (MODE == 39) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x[k]) : "v"(n[k]), "s"(a));
             if (MODE == 40) asm volatile("v_fma_f32 %0, %0, %1, %2 clamp" : "+v"(x[k]) : "v"(a), "v"(b));
             if (MODE == 11) asm volatile("v_cvt_f16_f32 %0, %0\n\tv_cvt_f32_f16 %0, %0" : "+v"(x[k]));
+            if (MODE == 41) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(n[k]) : "v"(n[0]));
+            if (MODE == 42) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(n[k]) : "v"(n[0]));
+            if (MODE == 43) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(m[k]) : "v"(n[k]), "v"(n[0]) : "vcc");
+            if (MODE == 44) asm volatile("v_lshlrev_b64 %0, 3, %0" : "+v"(m[k]));
+            if (MODE == 45) asm volatile("v_cvt_f64_i32 %0, %1" : "=v"(dd[k]) : "v"(n[k]));
+            if (MODE == 46) asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(n[k]) : "v"(dd[k]));
+            if (MODE == 47) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(n[k]) : "v"(n[0]));
+            if (MODE == 48) asm volatile("v_div_scale_f64 %0, vcc, %0, %1, %0" : "+v"(dd[k]) : "v"(da) : "vcc");
+            if (MODE == 49) asm volatile("v_div_fixup_f64 %0, %0, %1, %2" : "+v"(dd[k]) : "v"(da), "v"(db));
+            if (MODE == 50) asm volatile("v_add_co_u32 %0, vcc, %0, %1\n\tv_addc_co_u32 %2, vcc, 0, %2, vcc" : "+v"(n[k]) : "v"(n[0]), "v"(sg[k]) : "vcc");
+            if (MODE == 51) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, %0" : "+v"(n[k]));
+            if (MODE == 52) asm volatile("v_lshl_add_u64 %0, %0, 3, %1" : "+v"(m[k]) : "v"(m[0]));
+            if (MODE == 53) asm volatile("v_cvt_f32_i32 %0, %0" : "+v"(x[k]));
+            if (MODE == 54) asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(x[k]));
+            if (MODE == 55) asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(x[k]));
         }
     }
     float s = 0.0f;
@@ -138,5 +153,20 @@ int main()
     run<38>("v_lshl_or_b32", out, 1);
     run<39>("v_fma_mix_f32 f16hi,sgpr,f32", out, 2);
     run<40>("v_fma_f32 clamp", out, 2);
+    run<41>("v_mul_lo_u32", out, 1);
+    run<42>("v_mul_hi_u32", out, 1);
+    run<43>("v_mad_u64_u32", out, 1);
+    run<44>("v_lshlrev_b64", out, 1);
+    run<45>("v_cvt_f64_i32", out, 1);
+    run<46>("v_cvt_i32_f64", out, 1);
+    run<47>("v_mul_u32_u24", out, 1);
+    run<48>("v_div_scale_f64", out, 1);
+    run<49>("v_div_fixup_f64", out, 1);
+    run<50>("v_add_co_u32 + v_addc_co_u32", out, 1, 16);
+    run<51>("v_mbcnt_lo_u32_b32", out, 1);
+    run<52>("v_lshl_add_u64", out, 1);
+    run<53>("v_cvt_f32_i32", out, 1);
+    run<54>("v_cvt_i32_f32", out, 1);
+    run<55>("v_mov_b32 dpp quad_perm", out, 1);
     return 0;
 }

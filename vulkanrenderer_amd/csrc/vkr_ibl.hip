@@ -263,8 +263,8 @@ VKR_DEV f3 to_face_axes(int f, f3 r)
 template <bool TILED>
 VKR_DEV f3 fetch_footprint_on_face(const void *cube, int n, int face, int i0, int j0, float al, float be, const int (*edge_map)[5])
 {
-    // where the four texels are (byte offsets; the caller keeps cubes below 4 GiB), then the four loads in one go, then
-    // the corner's mean.  Products of small factors as 24-bit multiplies: the 32-bit one issues at a quarter of the rate.
+    // where the four texels are (32-bit byte offsets from the cube's base, which is the same for the whole wave: the
+    // caller keeps cubes below 4 GiB), then the four loads back to back, then the corner's mean
     unsigned at[4];
     bool whole = true;
     unsigned missing = 4;
