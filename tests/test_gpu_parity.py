@@ -278,6 +278,25 @@ def test_prefilter_bit_exact(gpu, oracle, rough):
     assert_bits_equal(P.f16_bits(out), want, f"prefilter roughness {rough}")
 
 
+def test_prefilter_large_launch_equals_small_launches(gpu, oracle):
+    """A prefilter launch of 65536 texels or more takes four texels per workgroup and the samples in two halves, a smaller
+    one two texels and all samples at once: the whole cube in one launch against the same cube row range by row range,
+    every texel, and sampled texels against the oracle (odd face size: the last group is cut short)."""
+    torch, P = _torch(), _passes()
+    n = 107
+    env = synth.make_env_cube(np.random.default_rng(12), 32)
+    dev_env = P.to_device_f16(env, gpu)
+    for rough in (0.0, 0.6):
+        whole = torch.zeros((6, n, n, 4), dtype=torch.float16, device=gpu)
+        parts = torch.zeros_like(whole)
+        P.prefilter(dev_env, whole, rough)
+        for r0 in range(0, 6 * n, 150):
+            P.prefilter(dev_env, parts, rough, rows=(r0, min(r0 + 150, 6 * n)))
+        assert np.array_equal(P.f16_bits(whole), P.f16_bits(parts)), rough
+    want = oracle.prefilter(env, n, 0.6).reshape(6 * n * n, 4)
+    assert_bits_equal(P.f16_bits(whole).reshape(6 * n * n, 4), want, "prefilter 107^2, roughness 0.6")
+
+
 @pytest.mark.parametrize("order", [0, 1, 2])
 def test_irradiance_bit_exact(gpu, oracle, order):
     torch, P = _torch(), _passes()

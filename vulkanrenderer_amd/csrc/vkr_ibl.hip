@@ -573,87 +573,98 @@ VKR_DEV float2 ggx_theta(int s, float rough)
     return make_float2(cos_t, sin_t);
 }
 
-// prefilter.frag:21-63, one workgroup per pair of neighbouring output texels.  Every lane evaluates four of the 1024
-// samples (environment colour and N.L) for both texels into LDS -- the sample's place on the GGX lobe depends on the
-// roughness only and is computed once for the pair; eight lanes -- red, green, blue and the weight total of each
-// texel -- then add them up in sample order, which is the shader's single running sum.
-static constexpr int PREFILTER_TEXELS = 2;
-template <bool TILED>
+// prefilter.frag:21-63, one workgroup per two or four neighbouring output texels; with four the 1024 samples go in two
+// halves.  Per half every lane evaluates its samples (environment colour and N.L) for the texels into LDS -- the
+// sample's place on the GGX lobe depends on the roughness only and is computed once for the group; one lane per
+// texel and channel -- red, green, blue and the weight total -- then adds the half to its running sum in sample
+// order, which is the shader's single running sum.  Four texels where the launch is large and bound by instruction
+// issue (mip 0: the sixteen summing lanes cost the instructions eight did, 0.80 -> 0.64 ms); two for the smaller
+// mips, which are bound by cache-line traffic and want the occupancy, and so that the small ones fill the chip.
+template <bool TILED, int PREFILTER_TEXELS>
 __global__ __launch_bounds__(256) void prefilter_texel_kernel(const void *env, int env_n, uint2 *out, int n, float rough, int row_begin, int n_texels, int per_xcd)
 {
-    __shared__ __align__(16) float term[PREFILTER_TEXELS][4][SAMPLE_COUNT];  // [0..2] environment colour, [3] N.L
+    constexpr int PREFILTER_PASS = 2 * SAMPLE_COUNT / PREFILTER_TEXELS;  // 32 KB of terms either way
+    __shared__ __align__(16) float term[PREFILTER_TEXELS][4][PREFILTER_PASS];  // [0..2] environment colour, [3] N.L
+    __shared__ __align__(16) float ones[16];
     __shared__ float result[PREFILTER_TEXELS][4];
     const int tid = threadIdx.x;
-    // Workgroups go to the 8 XCDs round-robin by id.  XCD x takes the pairs [x * per_xcd, (x + 1) * per_xcd) in row-major
+    // Workgroups go to the 8 XCDs round-robin by id.  XCD x takes the groups [x * per_xcd, (x + 1) * per_xcd) in row-major
     // order, so the workgroups resident on an XCD at any time are neighbours on the cube, their lobes overlap, and the
     // XCD's L2 serves most of their lookups.
     const int first = PREFILTER_TEXELS * ((int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3));
     if (first >= n_texels) return;
-    f3 N[PREFILTER_TEXELS], tangent[PREFILTER_TEXELS], bitangent[PREFILTER_TEXELS];
-#pragma unroll
-    for (int t = 0; t < PREFILTER_TEXELS; t++) {
-        const int texel = min(first + t, n_texels - 1);  // a pair beyond the last texel repeats it and stores it once
+    if (tid < 16) ones[tid] = 1.0f;
+    __shared__ float frame[PREFILTER_TEXELS][12];  // N, tangent, bitangent of each texel
+    if (tid < PREFILTER_TEXELS) {
+        const int texel = min(first + tid, n_texels - 1);  // a group beyond the last texel repeats it and stores it once
         const int i = texel % n, row = row_begin + texel / n;
         const int f = row / n, j = row - f * n;
-        N[t] = normalize3(face_dir(f, i, j, n));
-        tangent[t] = __builtin_fabsf(N[t].z) < 0.999f ? normalize3(mk3(-N[t].y, N[t].x, 0.0f))   // cross((0,0,1), N)
-                                                      : normalize3(mk3(0.0f, -N[t].z, N[t].y));  // cross((1,0,0), N)
-        bitangent[t] = cross3(N[t], tangent[t]);
-    }
-#ifndef VKR_PF_UNROLL
-#define VKR_PF_UNROLL 1
-#endif
-#pragma unroll VKR_PF_UNROLL
-    for (int m = 0; m < SAMPLE_COUNT / 256; m++) {
-        const int s = tid + 256 * m;
-        const float2 pcs = g_hammersley_cs[s];
-        const float2 tcs = ggx_theta(s, rough);
-        const float hx = pcs.x * tcs.y, hy = pcs.y * tcs.y, hz = tcs.x;
-#pragma unroll
-        for (int t = 0; t < PREFILTER_TEXELS; t++) {
-            const f3 H = normalize3_fast(mk3(fma_(N[t].x, hz, fma_(bitangent[t].x, hy, tangent[t].x * hx)),
-                                             fma_(N[t].y, hz, fma_(bitangent[t].y, hy, tangent[t].y * hx)),
-                                             fma_(N[t].z, hz, fma_(bitangent[t].z, hy, tangent[t].z * hx))));
-            const float vh2 = 2.0f * dot3(N[t], H);  // V = N
-            const f3 L = normalize3_fast(mk3(fma_(vh2, H.x, -N[t].x), fma_(vh2, H.y, -N[t].y), fma_(vh2, H.z, -N[t].z)));
-            const float NdotL = max0(dot3(N[t], L));
-            f3 c = mk3(0.0f, 0.0f, 0.0f);
-            if (NdotL > 0.0f) c = texcube_rgb_linear<TILED>(env, env_n, L);  // the shader's mip level is clamped to 0 by the sampler
-            term[t][0][s] = c.x; term[t][1][s] = c.y; term[t][2][s] = c.z; term[t][3][s] = NdotL;
-        }
+        const f3 N = normalize3(face_dir(f, i, j, n));
+        const f3 tangent = __builtin_fabsf(N.z) < 0.999f ? normalize3(mk3(-N.y, N.x, 0.0f))   // cross((0,0,1), N)
+                                                         : normalize3(mk3(0.0f, -N.z, N.y));  // cross((1,0,0), N)
+        const f3 bitangent = cross3(N, tangent);
+        float *fr = frame[tid];
+        fr[0] = N.x; fr[1] = N.y; fr[2] = N.z; fr[3] = tangent.x; fr[4] = tangent.y; fr[5] = tangent.z; fr[6] = bitangent.x; fr[7] = bitangent.y; fr[8] = bitangent.z;
     }
     __syncthreads();
-    if (tid < 4 * PREFILTER_TEXELS) {
-        const int t = tid >> 2, ch = tid & 3;
-        const float4 *mine = (const float4 *)term[t][ch], *wts = (const float4 *)term[t][3];
-        float acc = 0.0f;
-        // The running sum is one dependent fma per sample; the terms are read sixteen samples ahead, so that a step
-        // costs the fma's latency and not an LDS round trip.
-        constexpr int AHEAD = 4;
-        float4 c[AHEAD], wt[AHEAD];
-#pragma unroll
-        for (int u = 0; u < AHEAD; u++) { c[u] = mine[u]; wt[u] = wts[u]; }
-        for (int q = 0; q < SAMPLE_COUNT / 4; q += AHEAD) {
-            float4 cn[AHEAD], wn[AHEAD];
-            const int qn = min(q + AHEAD, SAMPLE_COUNT / 4 - AHEAD);
-#pragma unroll
-            for (int u = 0; u < AHEAD; u++) { cn[u] = mine[qn + u]; wn[u] = wts[qn + u]; }
-#pragma unroll
-            for (int u = 0; u < AHEAD; u++) {
-                float4 v = c[u];
-                if (ch == 3) v = make_float4(1.0f, 1.0f, 1.0f, 1.0f);  // totalWeight += NdotL
-                // A sample the shader skips (N.L <= 0) was stored as colour 0, weight 0: adding
-                // 0 * 0 leaves the running sum's bits unchanged, so no test is needed here.
-                acc = fma_(v.x, wt[u].x, acc);
-                acc = fma_(v.y, wt[u].y, acc);
-                acc = fma_(v.z, wt[u].z, acc);
-                acc = fma_(v.w, wt[u].w, acc);
+    // the sixteen summing lanes: texel tid / 4, channel tid % 4 (3: totalWeight += NdotL, as a product with a block of
+    // ones that the lane keeps re-reading, so that all sixteen run the same multiply-adds)
+    const int sum_t = (tid >> 2) & (PREFILTER_TEXELS - 1), sum_ch = tid & 3;
+    const float4 *const sum_mine = sum_ch == 3 ? (const float4 *)ones : (const float4 *)term[sum_t][sum_ch];
+    const float4 *const sum_wts = (const float4 *)term[sum_t][3];
+    const int sum_stride = sum_ch == 3 ? 0 : 1;
+    float acc = 0.0f;
+    for (int half = 0; half < SAMPLE_COUNT / PREFILTER_PASS; half++) {
+        if (half) __syncthreads();  // the sums of the first half have been taken
+#pragma unroll 1
+        for (int m = 0; m < PREFILTER_PASS / 256; m++) {
+            const int sl = tid + 256 * m, s = half * PREFILTER_PASS + sl;
+            const float2 pcs = g_hammersley_cs[s];
+            const float2 tcs = ggx_theta(s, rough);
+            const float hx = pcs.x * tcs.y, hy = pcs.y * tcs.y, hz = tcs.x;
+#pragma unroll 1
+            for (int t = 0; t < PREFILTER_TEXELS; t++) {
+                const float *fr = frame[t];
+                const f3 N = mk3(fr[0], fr[1], fr[2]), tangent = mk3(fr[3], fr[4], fr[5]), bitangent = mk3(fr[6], fr[7], fr[8]);
+                const f3 H = normalize3_fast(mk3(fma_(N.x, hz, fma_(bitangent.x, hy, tangent.x * hx)),
+                                                 fma_(N.y, hz, fma_(bitangent.y, hy, tangent.y * hx)),
+                                                 fma_(N.z, hz, fma_(bitangent.z, hy, tangent.z * hx))));
+                const float vh2 = 2.0f * dot3(N, H);  // V = N
+                const f3 L = normalize3_fast(mk3(fma_(vh2, H.x, -N.x), fma_(vh2, H.y, -N.y), fma_(vh2, H.z, -N.z)));
+                const float NdotL = max0(dot3(N, L));
+                f3 c = mk3(0.0f, 0.0f, 0.0f);
+                if (NdotL > 0.0f) c = texcube_rgb_linear<TILED>(env, env_n, L);  // the shader's mip level is clamped to 0 by the sampler
+                term[t][0][sl] = c.x; term[t][1][sl] = c.y; term[t][2][sl] = c.z; term[t][3][sl] = NdotL;
             }
-#pragma unroll
-            for (int u = 0; u < AHEAD; u++) { c[u] = cn[u]; wt[u] = wn[u]; }
         }
-        result[t][ch] = acc;
+        __syncthreads();
+        if (tid < 4 * PREFILTER_TEXELS) {
+            // The running sum is one dependent fma per sample; the terms are read sixteen samples ahead, so that a step
+            // costs the fma's latency and not an LDS round trip.  A sample the shader skips (N.L <= 0) was stored as
+            // colour 0, weight 0: adding 0 * 0 leaves the running sum's bits unchanged, so no test is needed here.
+            constexpr int AHEAD = 4, QUADS = PREFILTER_PASS / 4;
+            float4 c[AHEAD], wt[AHEAD];
+#pragma unroll
+            for (int u = 0; u < AHEAD; u++) { c[u] = sum_mine[u]; wt[u] = sum_wts[u]; }
+            for (int q = 0; q < QUADS; q += AHEAD) {
+                float4 cn[AHEAD], wn[AHEAD];
+                const int qn = min(q + AHEAD, QUADS - AHEAD);
+                const float4 *next = sum_mine + qn * sum_stride;
+#pragma unroll
+                for (int u = 0; u < AHEAD; u++) { cn[u] = next[u]; wn[u] = sum_wts[qn + u]; }
+#pragma unroll
+                for (int u = 0; u < AHEAD; u++) {
+                    acc = fma_(c[u].x, wt[u].x, acc);
+                    acc = fma_(c[u].y, wt[u].y, acc);
+                    acc = fma_(c[u].z, wt[u].z, acc);
+                    acc = fma_(c[u].w, wt[u].w, acc);
+                }
+#pragma unroll
+                for (int u = 0; u < AHEAD; u++) { c[u] = cn[u]; wt[u] = wn[u]; }
+            }
+        }
     }
+    if (tid < 4 * PREFILTER_TEXELS) result[sum_t][sum_ch] = acc;
     __syncthreads();
     if (tid < PREFILTER_TEXELS && first + tid < n_texels) {
         const int texel = first + tid;
@@ -865,9 +876,12 @@ extern "C" int32_t vkr_ibl_prefilter(const void *env, int32_t env_n, int32_t env
     if ((rc = ensure_tables()) != VKR_OK) return rc;
     if (row_end == row_begin) return VKR_OK;
     const int n_texels = n * (row_end - row_begin);
-    const int per_xcd = ((n_texels + PREFILTER_TEXELS - 1) / PREFILTER_TEXELS + 7) / 8;  // pairs of texels per XCD
+    const int group = n_texels >= 65536 ? 4 : 2;                // output texels per workgroup
+    const int per_xcd = ((n_texels + group - 1) / group + 7) / 8;  // groups of texels per XCD
     dim3 grid(8 * per_xcd);
-    hipLaunchKernelGGL(tiled ? prefilter_texel_kernel<true> : prefilter_texel_kernel<false>, grid, dim3(256), 0, as_stream(stream), env, env_n, (uint2 *)out, n, roughness, row_begin, n_texels, per_xcd);
+    auto kernel = group == 4 ? (tiled ? prefilter_texel_kernel<true, 4> : prefilter_texel_kernel<false, 4>)
+                             : (tiled ? prefilter_texel_kernel<true, 2> : prefilter_texel_kernel<false, 2>);
+    hipLaunchKernelGGL(kernel, grid, dim3(256), 0, as_stream(stream), env, env_n, (uint2 *)out, n, roughness, row_begin, n_texels, per_xcd);
     return launch_status("vkr_ibl_prefilter");
 }
 
