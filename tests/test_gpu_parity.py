@@ -279,7 +279,7 @@ def test_prefilter_bit_exact(gpu, oracle, rough):
 
 
 def test_prefilter_large_launch_equals_small_launches(gpu, oracle):
-    """A prefilter launch of 65536 texels or more takes four texels per workgroup and the samples in two halves, a smaller
+    """A prefilter launch of 65536 texels or more takes sixteen texels per workgroup and the samples in eight passes, a smaller
     one two texels and all samples at once: the whole cube in one launch against the same cube row range by row range,
     every texel, and sampled texels against the oracle (odd face size: the last group is cut short)."""
     torch, P = _torch(), _passes()

@@ -573,13 +573,14 @@ VKR_DEV float2 ggx_theta(int s, float rough)
     return make_float2(cos_t, sin_t);
 }
 
-// prefilter.frag:21-63, one workgroup per two or four neighbouring output texels; with four the 1024 samples go in two
-// halves.  Per half every lane evaluates its samples (environment colour and N.L) for the texels into LDS -- the
-// sample's place on the GGX lobe depends on the roughness only and is computed once for the group; one lane per
-// texel and channel -- red, green, blue and the weight total -- then adds the half to its running sum in sample
-// order, which is the shader's single running sum.  Four texels where the launch is large and bound by instruction
-// issue (mip 0: the sixteen summing lanes cost the instructions eight did, 0.80 -> 0.64 ms); two for the smaller
-// mips, which are bound by cache-line traffic and want the occupancy, and so that the small ones fill the chip.
+// prefilter.frag:21-63, one workgroup per two or sixteen neighbouring output texels; with sixteen the 1024 samples go in
+// eight passes of 128.  Per pass every lane evaluates its samples (environment colour and N.L) for its texels into
+// LDS -- the sample's place on the GGX lobe depends on the roughness only and is computed once per lane; one lane per
+// texel and channel -- red, green, blue and the weight total -- then adds the pass to its running sum in sample
+// order, which is the shader's single running sum.  Sixteen texels where the launch is large and bound by instruction
+// issue (mip 0: the 64 summing lanes cost the instructions, and the other waves the waiting, that eight did: 0.80 ->
+// 0.52 ms); two for the smaller mips, which are bound by cache-line traffic and want the occupancy, and so that the
+// small ones fill the chip.
 template <bool TILED, int PREFILTER_TEXELS>
 __global__ __launch_bounds__(256) void prefilter_texel_kernel(const void *env, int env_n, uint2 *out, int n, float rough, int row_begin, int n_texels, int per_xcd)
 {
@@ -616,14 +617,18 @@ __global__ __launch_bounds__(256) void prefilter_texel_kernel(const void *env, i
     float acc = 0.0f;
     for (int half = 0; half < SAMPLE_COUNT / PREFILTER_PASS; half++) {
         if (half) __syncthreads();  // the sums of the first half have been taken
+        // a pass of 256 samples or more: every lane takes all texels of its samples; a shorter one: the lanes share the
+        // texels of a sample between them
+        constexpr int LANES = PREFILTER_PASS < 256 ? PREFILTER_PASS : 256, SHARE = 256 / LANES, MINE = PREFILTER_TEXELS / SHARE;
+        const int t_first = (tid / LANES) * MINE;
 #pragma unroll 1
-        for (int m = 0; m < PREFILTER_PASS / 256; m++) {
-            const int sl = tid + 256 * m, s = half * PREFILTER_PASS + sl;
+        for (int m = 0; m < PREFILTER_PASS / LANES; m++) {
+            const int sl = tid % LANES + LANES * m, s = half * PREFILTER_PASS + sl;
             const float2 pcs = g_hammersley_cs[s];
             const float2 tcs = ggx_theta(s, rough);
             const float hx = pcs.x * tcs.y, hy = pcs.y * tcs.y, hz = tcs.x;
 #pragma unroll 1
-            for (int t = 0; t < PREFILTER_TEXELS; t++) {
+            for (int t = t_first; t < t_first + MINE; t++) {
                 const float *fr = frame[t];
                 const f3 N = mk3(fr[0], fr[1], fr[2]), tangent = mk3(fr[3], fr[4], fr[5]), bitangent = mk3(fr[6], fr[7], fr[8]);
                 const f3 H = normalize3_fast(mk3(fma_(N.x, hz, fma_(bitangent.x, hy, tangent.x * hx)),
@@ -876,10 +881,10 @@ extern "C" int32_t vkr_ibl_prefilter(const void *env, int32_t env_n, int32_t env
     if ((rc = ensure_tables()) != VKR_OK) return rc;
     if (row_end == row_begin) return VKR_OK;
     const int n_texels = n * (row_end - row_begin);
-    const int group = n_texels >= 65536 ? 4 : 2;                // output texels per workgroup
+    const int group = n_texels >= 65536 ? 16 : 2;               // output texels per workgroup
     const int per_xcd = ((n_texels + group - 1) / group + 7) / 8;  // groups of texels per XCD
     dim3 grid(8 * per_xcd);
-    auto kernel = group == 4 ? (tiled ? prefilter_texel_kernel<true, 4> : prefilter_texel_kernel<false, 4>)
+    auto kernel = group == 16 ? (tiled ? prefilter_texel_kernel<true, 16> : prefilter_texel_kernel<false, 16>)
                              : (tiled ? prefilter_texel_kernel<true, 2> : prefilter_texel_kernel<false, 2>);
     hipLaunchKernelGGL(kernel, grid, dim3(256), 0, as_stream(stream), env, env_n, (uint2 *)out, n, roughness, row_begin, n_texels, per_xcd);
     return launch_status("vkr_ibl_prefilter");
