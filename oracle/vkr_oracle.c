@@ -854,10 +854,13 @@ static void shadow_raster(const float (*clip)[4], const float (*world)[4], const
             if (!(zs >= 0.0 && zs <= t.D)) continue;
             float depth;
             if (world) { /* point_shadow.frag:11-16 on the interpolated world position */
+                /* Coverage is decided in binary64 (above); the attribute is interpolated the way graphics hardware does it,
+                 * in binary32: the edge values rounded to binary32 are the perspective-correct weights, sum(Ei * Pi) * (1 / sum(Ei)). */
                 float p[3];
-                const double inv_s = 1.0 / s;  /* one division per sample: sum(Ei * Pi) * (1 / sum(Ei)) */
+                const float f0 = (float)e0, f1 = (float)e1, f2 = (float)e2;
+                const float inv_s = rcpf_((f0 + f1) + f2);
                 for (int k = 0; k < 3; k++)
-                    p[k] = (float)(fma(e2, (double)world[2][k], fma(e1, (double)world[1][k], e0 * (double)world[0][k])) * inv_s);
+                    p[k] = fmaf(f2, world[2][k], fmaf(f1, world[1][k], f0 * world[0][k])) * inv_s;
                 depth = point_shadow_depth(p, light_pos, inv_far);
             } else {
                 depth = (float)(zs * inv_D) + 0.0f; /* z / w of the fixed-function pipeline as z * (1/w) (-0 becomes +0) */

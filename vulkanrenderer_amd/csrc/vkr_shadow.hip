@@ -6,7 +6,7 @@
 // A texel belongs to a triangle when its centre lies inside the projected back-facing triangle
 // and the depth there passes the 0 <= z <= w clip -- the homogeneous binary64 rule of the
 // light-volume coverage kernel -- and the world position the fragment shader receives is the
-// perspective-correct interpolation sum(Ei * Pi) * (1 / sum(Ei)).  The stored value is the minimum over
+// perspective-correct interpolation sum(Ei * Pi) * (1 / sum(Ei)) in binary32 (the edge values Ei rounded to it).  The stored value is the minimum over
 // all covering triangles (atomicMin on the bits of a non-negative float), so the result does not
 // depend on the order of triangles, lanes or launches.
 //
@@ -78,11 +78,14 @@ VKR_DEV void shadow_raster(bool valid, const float (&clip)[3][4], const float (&
         if (!(zs >= 0.0 && zs <= t.D)) return;
         float depth;
         if (POINT) {  // point_shadow.frag:11-16 on the interpolated world position
+            // coverage was decided in binary64; the attribute is interpolated as graphics hardware does it, in binary32:
+            // the edge values rounded to binary32 are the perspective-correct weights
             float pw[3];
-            const double inv_s = 1.0 / s;
+            const float f0 = (float)e0, f1 = (float)e1, f2 = (float)e2;
+            const float inv_s = rcp_rn_checked((f0 + f1) + f2);
 #pragma unroll
             for (int k = 0; k < 3; k++)
-                pw[k] = (float)(__builtin_fma(e2, (double)wp[2][k], __builtin_fma(e1, (double)wp[1][k], e0 * (double)wp[0][k])) * inv_s);
+                pw[k] = fma_(f2, wp[2][k], fma_(f1, wp[1][k], f0 * wp[0][k])) * inv_s;
             const f3 d = mk3(pw[0] - light_pos[0], pw[1] - light_pos[1], pw[2] - light_pos[2]);
             depth = sqrt_rn_checked(dot3(d, d)) * inv_far;
         } else {
