@@ -1506,8 +1506,11 @@ ORC_API void orc_gbuffer(const orc_gpass_args *a)
             for (int i = 0; i < 3; i++) { tr.a[i] = -tr.a[i]; tr.b[i] = -tr.b[i]; tr.c[i] = -tr.c[i]; }
             const double xn = fma((double)x + 0.5, sx, -1.0), yn = fma((double)(a->row0 + y) + 0.5, sy, -1.0);
             const double e0 = cov_edge(&tr, 0, xn, yn), e1 = cov_edge(&tr, 1, xn, yn), e2 = cov_edge(&tr, 2, xn, yn);
-            const double inv_s = 1.0 / ((e0 + e1) + e2);  /* one division per pixel */
-#define GP_LERP(field, k) ((float)(fma(e2, (double)v[2].field[k], fma(e1, (double)v[1].field[k], e0 * (double)v[0].field[k])) * inv_s))
+            /* attributes are interpolated in binary32, as in the shadow pass: the binary64 edge values rounded to binary32
+             * are the perspective-correct weights, sum(Ei * Ai) * (1 / sum(Ei)) */
+            const float f0 = (float)e0, f1 = (float)e1, f2 = (float)e2;
+            const float inv_s = rcpf_((f0 + f1) + f2);  /* one division per pixel */
+#define GP_LERP(field, k) (fmaf(f2, v[2].field[k], fmaf(f1, v[1].field[k], f0 * v[0].field[k])) * inv_s)
             const float u = GP_LERP(uv, 0), vv = GP_LERP(uv, 1);
             float pos[4], tbn[9];
             for (int k = 0; k < 4; k++) pos[k] = GP_LERP(pos, k);

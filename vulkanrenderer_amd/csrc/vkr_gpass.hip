@@ -178,8 +178,11 @@ __global__ __launch_bounds__(256) void gpass_resolve_kernel(const GpassParams p)
     const double sx = 2.0 / (double)p.width, sy = 2.0 / (double)p.frame_rows;
     const double xn = __builtin_fma((double)x + 0.5, sx, -1.0), yn = __builtin_fma((double)(p.row0 + y) + 0.5, sy, -1.0);
     const double e0 = s_edge(tr, 0, xn, yn), e1 = s_edge(tr, 1, xn, yn), e2 = s_edge(tr, 2, xn, yn);
-    const double inv_s = 1.0 / ((e0 + e1) + e2);  // one division per pixel
-    auto lerp = [&](float a0, float a1, float a2) { return (float)(__builtin_fma(e2, (double)a2, __builtin_fma(e1, (double)a1, e0 * (double)a0)) * inv_s); };
+    // attributes are interpolated in binary32, as in the shadow pass: the binary64 edge values rounded to binary32 are the
+    // perspective-correct weights
+    const float f0 = (float)e0, f1 = (float)e1, f2 = (float)e2;
+    const float inv_s = rcp_rn_checked((f0 + f1) + f2);  // one division per pixel
+    auto lerp = [&](float a0, float a1, float a2) { return fma_(f2, a2, fma_(f1, a1, f0 * a0)) * inv_s; };
     const float u = lerp(v[0].uv[0], v[1].uv[0], v[2].uv[0]), vv = lerp(v[0].uv[1], v[1].uv[1], v[2].uv[1]);
     float pos[4], tbn[9];
 #pragma unroll
