@@ -103,7 +103,16 @@ public sealed unsafe class HipRenderer : IDisposable
     bool hasVolumeMesh;
     public List<Light> Lights = new();   // VulkanRenderer.cs:65
 
-    public HipRenderer(in VkrConfig config) => Check(Native.vkr_create(config, out ctx));
+    // VKR_ABI_VERSION of the vkr_hip.h these declarations were written against: a library of another revision
+    // would misread the structs passed below
+    public const int AbiVersion = 3;
+
+    public HipRenderer(in VkrConfig config)
+    {
+        if (Native.vkr_abi_version() != AbiVersion)
+            throw new Exception($"libvkr_hip has interface version {Native.vkr_abi_version()}, this binding needs {AbiVersion}");
+        Check(Native.vkr_create(config, out ctx));
+    }
 
     internal static void Check(int rc)
     {

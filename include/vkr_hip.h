@@ -85,6 +85,12 @@ typedef struct VkrLightInfo {
 #define VKR_ENV_LAYOUT_LINEAR 0    /* [face][row][column], tight */
 #define VKR_ENV_LAYOUT_TILED_4X4 1 /* each face as row-major 4x4-texel tiles of 128 bytes; face size % 4 == 0;
                                       made from the linear layout by vkr_tile_rgba16f_faces() */
+#define VKR_ENV_LAYOUT_FOOTPRINT_TILES 2
+/* The third layout, read by vkr_ibl_irradiance_by_region_rows only and made by vkr_tile_rgba16f_footprints(): "footprint
+ * tiles" -- 4x4-texel tiles of 128 bytes at a stride of THREE texels in both directions over each face extended by a
+ * one-texel apron (the neighbouring faces' texels, as seamless cube filtering folds them), (n / 3 + 1)^2 tiles per face,
+ * row-major by tile: tile (k, m) holds the texels (3k-1 .. 3k+2) x (3m-1 .. 3m+2).  The 2x2 footprint of any LINEAR
+ * lookup then lies inside one tile (one cache line), at the price of 16/9 of the memory. */
 
 #define VKR_WRAP_REPEAT 0 /* textureSampler, VulkanHelper.cs:123-154 */
 #define VKR_WRAP_CLAMP 1  /* bloomSampler,   VulkanHelper.cs:156-187 */
@@ -102,7 +108,23 @@ typedef struct VkrLightInfo {
                                        64 accumulators are combined pairwise (partner = index xor 32, 16, .. 1) and the
                                        region sums added in region order.  Nearly three times as fast at 2048^2 faces (the
                                        lookups hit the cache); differs from the shader's order in rounding only */
+#define VKR_IRRADIANCE_BY_REGION_ROWS 3 /* samples grouped by region again, the regions cut for the footprint-tile layout
+                                       (the base texel of a lookup's 2x2 footprint, shifted by one to lie in [0, n]^2, in
+                                       cells of 3x3 positions, C = ceil(cells / ceil(cells / 128)) cells per region side
+                                       with cells = n / 3 + 1, regions numbered (row * per_side + column) * 6 + face); within
+                                       a region every phi row of the shader's loop is summed on its own (theta ascending),
+                                       the row sums are added in phi order and the region sums in region order.  The
+                                       fastest order; differs from the shader's order in rounding only */
+#define VKR_IRRADIANCE_FASTEST (-1) /* layer 2 only: the library's choice, currently VKR_IRRADIANCE_BY_REGION_ROWS */
 
+/* Version of this interface: it changes whenever a struct below gains, loses or re-orders a field, an argument
+ * list changes, or a layout constant changes its meaning -- anything that makes a host built against an older
+ * header pass memory the library would misread.  A host compares vkr_abi_version() (what the loaded library was
+ * built with) against the VKR_ABI_VERSION it was compiled with and refuses to go on when they differ.
+ * History: 1 the first interface; 2 VkrShadeArgs.coverage_flags, VkrCoverageArgs.light_flags,
+ * VkrConfig.frame_rows / row0, VKR_CUBE_LAYOUT_TILED_8X4 stores its tiles column by column;
+ * 3 VKR_IRRADIANCE_BY_REGION_ROWS and the layer-2 default order, the workspace word of the by-region call. */
+#define VKR_ABI_VERSION 3
 VKR_EXPORT const char *vkr_last_error(void);
 VKR_EXPORT int32_t vkr_abi_version(void);
 /* Number of gfx950 devices visible to the process (0 if none); never fails. */
@@ -226,8 +248,10 @@ typedef struct VkrGpassArgs {
 VKR_EXPORT int64_t vkr_gbuffer_workspace_bytes(int32_t width, int32_t rows, int32_t n_draws);
 VKR_EXPORT int32_t vkr_gbuffer(const VkrGpassArgs *args, void *stream);
 
-/* vkr_gbuffer for callers that cannot allocate device memory (code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  The visibility keys and
+/* vkr_gbuffer for callers that cannot allocate device memory (tight serving loops, harnesses that forbid
+ * hipMalloc).  It has no counterpart in the reference.  It is not meant for recording into a HIP graph: the draw
+ * records are copied from the host array with an asynchronous copy and the launches are sized from host-side
+ * triangle counts, so a replayed graph would draw the records of the call that was captured.  The visibility keys and
  * the draw records live in a fixed array inside the library's code object instead of a workspace
  * (args->workspace and args->workspace_bytes are ignored), so the call allocates and frees nothing; each GPU
  * the library is loaded on holds VKR_GBUFFER_STATIC_MAX_PIXELS * 8 bytes + 16 KiB for it until the process
@@ -322,6 +346,15 @@ VKR_EXPORT int32_t vkr_ibl_irradiance(const void *env, int32_t env_n, int32_t en
  * the kernel's culling has a flaw; vkr_create_irradiance_cubemap checks it. */
 VKR_EXPORT int64_t vkr_ibl_irradiance_by_region_workspace_bytes(int32_t env_n, int32_t n, int32_t row_begin, int32_t row_end);
 VKR_EXPORT int32_t vkr_ibl_irradiance_by_region(const void *env, int32_t env_n, int32_t env_layout, void *out, int32_t n,
+                           int32_t row_begin, int32_t row_end, void *workspace, int64_t workspace_bytes, void *stream);
+/* The same six draws summed in the VKR_IRRADIANCE_BY_REGION_ROWS order, from the environment in footprint tiles
+ * (vkr_tile_rgba16f_footprints of the whole cube into vkr_env_footprint_tiles_bytes(env_n) bytes, 8-byte aligned; -1: bad
+ * size).  Sizes, workspace and its check word as for vkr_ibl_irradiance_by_region; a texel whose samples were not all
+ * found is also written as NaN (by both calls).  Neither call has a counterpart in the reference beyond the pass itself. */
+VKR_EXPORT int64_t vkr_env_footprint_tiles_bytes(int32_t n);
+VKR_EXPORT int32_t vkr_tile_rgba16f_footprints(const void *linear_cube, void *tiles, int32_t n, void *stream);
+VKR_EXPORT int64_t vkr_ibl_irradiance_by_region_rows_workspace_bytes(int32_t env_n, int32_t n, int32_t row_begin, int32_t row_end);
+VKR_EXPORT int32_t vkr_ibl_irradiance_by_region_rows(const void *env_tiles, int32_t env_n, void *out, int32_t n,
                            int32_t row_begin, int32_t row_end, void *workspace, int64_t workspace_bytes, void *stream);
 /* Replaces the six draws of one mip of CreatePrefilteredCubemap (VulkanRenderer.cs:855-884). */
 VKR_EXPORT int32_t vkr_ibl_prefilter(const void *env, int32_t env_n, int32_t env_layout, void *out, int32_t n, float roughness,
@@ -427,8 +460,10 @@ VKR_EXPORT int32_t vkr_pass_postprocess(vkr_ctx *ctx);
  * stages in the reference's submission order (the numbering below), then advances the frame index like EndFrame.
  * vkr_stage_draw records all draws the reference records into that stage (per light for the point-shadow stage and
  * the light volumes; per draw call for the geometry and shadow stages).  A render pass without draws leaves its
- * attachments at the reference's clear values; a stage that recorded nothing leaves its images as they are (uploaded,
- * or from an earlier frame).  Every bloom image is stored, as in the reference (vkr_end_frame stores none).
+ * attachments at the reference's clear values -- also when vkr_stage_draw was called in a frame with no vkr_draw_model
+ * calls, for the two shadow stages and the geometry stage: their draw loops are then empty, as in the reference.  A
+ * stage that recorded nothing leaves its images as they are (uploaded, or from an earlier frame): a host that uploads
+ * the G-buffer or the shadow maps instead of drawing them does not record those stages.  Every bloom image is stored, as in the reference (vkr_end_frame stores none).
  * Calls out of order fail with VKR_ERR_ORDER, as the reference throws on a failed vkBegin/EndCommandBuffer
  * (RenderStage.cs:106-121).  vkr_begin_frame resets every stage (VulkanRenderer.cs:307-314). */
 #define VKR_STAGE_POINT_SHADOW 0  /* pointShadowRenderStages[0 .. Lights.Count) */

@@ -90,7 +90,14 @@ class HipRenderer {
 public:
     std::vector<Light> Lights;  // VulkanRenderer.cs:65
 
-    explicit HipRenderer(const VkrConfig &config) { check(vkr_create(&config, &ctx_)); }
+    explicit HipRenderer(const VkrConfig &config)
+    {
+        // a library built from another revision of vkr_hip.h would misread the structs this host passes
+        if (vkr_abi_version() != VKR_ABI_VERSION)
+            throw Error(VKR_ERR_UNSUPPORTED, "libvkr_hip: the loaded library has interface version " + std::to_string(vkr_abi_version()) +
+                                             ", this host was compiled against " + std::to_string(VKR_ABI_VERSION));
+        check(vkr_create(&config, &ctx_));
+    }
     ~HipRenderer() { Dispose(); }
     HipRenderer(const HipRenderer &) = delete;
     HipRenderer &operator=(const HipRenderer &) = delete;

@@ -1120,6 +1120,36 @@ static inline int cube_lookup_region(int n, v3 r)
     return ((j0 >> 9) * per_side + (i0 >> 9)) * 6 + face;
 }
 
+/* Order = 3 of orc_irradiance cuts the faces differently.  The base texel (i0, j0) of a lookup's 2x2 footprint lies in
+ * [-1, n-1]^2 (-1: the footprint reaches over the face's edge); shifted by one, (I0, J0) = (i0 + 1, j0 + 1) lies in
+ * [0, n]^2.  Cells of 3 x 3 such positions (n/3 + 1 per side) are grouped into square regions of `cells_per_region`
+ * cells per side, chosen as the most even split that keeps a region at or below 128 cells (384 texels) per side;
+ * regions are numbered (row * per_side + column) * 6 + face. */
+static inline void cube_region_grid3(int n, int *per_side, int *cells_per_region)
+{
+    int cells = n / 3 + 1;
+    *per_side = (cells + 127) / 128;
+    *cells_per_region = (cells + *per_side - 1) / *per_side;
+}
+
+static inline int cube_lookup_region3(int n, v3 r)
+{
+    int face; float s, t;
+    cube_st(r, &face, &s, &t);
+    float x = s * (float)n - 0.5f, y = t * (float)n - 0.5f;
+    int I0 = f2i_sat(floorf(x)) + 1, J0 = f2i_sat(floorf(y)) + 1;
+    I0 = I0 < 0 ? 0 : (I0 > n ? n : I0);   /* only non-finite directions ever leave [0, n] */
+    J0 = J0 < 0 ? 0 : (J0 > n ? n : J0);
+    int per_side, cpr;
+    cube_region_grid3(n, &per_side, &cpr);
+    return (((J0 / 3) / cpr) * per_side + (I0 / 3) / cpr) * 6 + face;
+}
+
+ORC_API int orc_cube_lookup_region3(int n, const float *dir3)
+{
+    return cube_lookup_region3(n, v3_(dir3[0], dir3[1], dir3[2]));
+}
+
 /* irradiance.frag:10-39.  The loop variables are binary32 running sums, which gives 252 phi
  * values and 63 theta values.  order = 0: one running sum over all samples, phi outer / theta
  * inner, as the shader does.  order = 1: each phi slice is summed on its own (theta ascending,
@@ -1129,7 +1159,10 @@ static inline int cube_lookup_region(int n, v3 r)
  * k-th sample (phi outer / theta inner order) goes to accumulator k mod 64, the 64 accumulators are
  * combined pairwise (partner = index xor 32, 16, 8, 4, 2, 1), and the region sums are added in
  * region order -- the order a kernel that works through the environment region by region, so that
- * its lookups hit the cache, can reproduce bit for bit. */
+ * its lookups hit the cache, can reproduce bit for bit.  order = 3: the samples are grouped by the region of
+ * cube_lookup_region3; within a (texel, region) pair every phi row is summed on its own (theta ascending, starting
+ * from 0, only the samples that belong to the region), the row sums are added in phi order, and the region sums in
+ * region order -- what a kernel that gives every lane a phi row of a pair reproduces bit for bit. */
 ORC_API void orc_irradiance(const uint16_t *env, int env_n, uint16_t *out, int n, int order)
 {
     float phis[512], thetas[128];
@@ -1174,7 +1207,41 @@ ORC_API void orc_irradiance(const uint16_t *env, int env_n, uint16_t *out, int n
                     }
                     free(lanes); free(count);
                 }
-                for (int a = 0; a < nphi && order != 2; a++) {
+                if (order == 3) {
+                    int per_side, cpr;
+                    cube_region_grid3(env_n, &per_side, &cpr);
+                    const int n_regions = 6 * per_side * per_side;
+                    float (*pair)[3] = calloc((size_t)n_regions, sizeof(*pair));   /* sum of the rows added so far */
+                    float (*row)[3] = calloc((size_t)n_regions, sizeof(*row));     /* the current phi row's sum */
+                    unsigned char *touched = calloc((size_t)n_regions, 1);
+                    int *list = malloc((size_t)n_regions * sizeof(int));
+                    for (int a = 0; a < nphi; a++) {
+                        float cp = cosf(phis[a]), sp = sinf(phis[a]);
+                        int n_list = 0;
+                        for (int b = 0; b < ntheta; b++) {
+                            float st = sinf(thetas[b]), ct = cosf(thetas[b]);
+                            float tx = st * cp, ty = st * sp, tz = ct;
+                            v3 sv = v3_(fmaf(tz, N.x, fmaf(ty, up.x, tx * right.x)),
+                                        fmaf(tz, N.y, fmaf(ty, up.y, tx * right.y)),
+                                        fmaf(tz, N.z, fmaf(ty, up.z, tx * right.z)));
+                            v3 c = texcube_rgb_linear(env, env_n, sv);
+                            int r = cube_lookup_region3(env_n, sv);
+                            if (!touched[r]) { touched[r] = 1; list[n_list++] = r; row[r][0] = row[r][1] = row[r][2] = 0.0f; }
+                            row[r][0] = fmaf(c.x * ct, st, row[r][0]);
+                            row[r][1] = fmaf(c.y * ct, st, row[r][1]);
+                            row[r][2] = fmaf(c.z * ct, st, row[r][2]);
+                        }
+                        for (int q = 0; q < n_list; q++) {
+                            int r = list[q];
+                            for (int k = 0; k < 3; k++) pair[r][k] = pair[r][k] + row[r][k];
+                            touched[r] = 0;
+                        }
+                    }
+                    for (int r = 0; r < n_regions; r++)
+                        for (int k = 0; k < 3; k++) irr[k] = irr[k] + pair[r][k];
+                    free(pair); free(row); free(touched); free(list);
+                }
+                for (int a = 0; a < nphi && order < 2; a++) {
                     float cp = cosf(phis[a]), sp = sinf(phis[a]);
                     float part[3] = {0, 0, 0};
                     float *acc = order ? part : irr;

@@ -40,7 +40,9 @@ def test_struct_layouts_match_the_reference_blocks():
 
 def test_version_and_argument_errors_without_a_device():
     lib = _lib.load()
-    assert lib.vkr_abi_version() == 1
+    header = open(os.path.join(ROOT, "include", "vkr_hip.h")).read()
+    declared = int(re.search(r"#define\s+VKR_ABI_VERSION\s+(\d+)", header).group(1))
+    assert lib.vkr_abi_version() == declared == _lib.ABI_VERSION  # library, header and binding agree
     assert lib.vkr_device_count() >= 0
     # argument validation happens before any HIP call
     assert lib.vkr_shade(None, None) == _lib.VKR_ERR_INVALID

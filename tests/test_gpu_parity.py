@@ -124,7 +124,7 @@ def test_post_chain_and_ibl_against_reference_shader_vectors(gpu):
     assert close(cube.float().cpu().numpy(), g["equirect_cube"]).all()
     env = P.to_device_f16(g["env"], gpu)
     irr = torch.empty((6, 2, 2, 4), dtype=torch.float16, device=gpu)
-    for order in (_lib.IRRADIANCE_SEQUENTIAL, _lib.IRRADIANCE_PHI_SLICES, _lib.IRRADIANCE_BY_REGION):
+    for order in (_lib.IRRADIANCE_SEQUENTIAL, _lib.IRRADIANCE_PHI_SLICES, _lib.IRRADIANCE_BY_REGION, _lib.IRRADIANCE_BY_REGION_ROWS):
         P.irradiance(env, irr, order)
         got = irr.float().cpu().numpy()
         for (f, i, j), want in zip(g["irradiance_texels"], g["irradiance"]):
@@ -297,7 +297,7 @@ def test_prefilter_large_launch_equals_small_launches(gpu, oracle):
     assert_bits_equal(P.f16_bits(whole).reshape(6 * n * n, 4), want, "prefilter 107^2, roughness 0.6")
 
 
-@pytest.mark.parametrize("order", [0, 1, 2])
+@pytest.mark.parametrize("order", [0, 1, 2, 3])
 def test_irradiance_bit_exact(gpu, oracle, order):
     torch, P = _torch(), _passes()
     env = synth.make_env_cube(np.random.default_rng(4), 16)
@@ -367,6 +367,88 @@ def test_irradiance_by_region_of_a_large_environment(gpu, oracle):
     assert lib.vkr_ibl_irradiance_by_region_workspace_bytes(64, 4, 0, 25) == -1
     empty = torch.zeros((6, n, n, 4), dtype=torch.float16, device=gpu)
     P.irradiance_by_region(dev_env, empty, (5, 5), layout)  # no rows: nothing is written
+    assert (empty == 0).all()
+
+
+def test_footprint_tiles_hold_every_footprint_whole(gpu, oracle):
+    """vkr_tile_rgba16f_footprints against the layout's definition: tile (k, m) of a face holds the texels
+    (3k-1 .. 3k+2) x (3m-1 .. 3m+2), those beyond an edge folded from the neighbouring face as the oracle's cube_fold
+    folds them, those beyond a corner of the cube (or beyond the apron) zero."""
+    torch, P = _torch(), _passes()
+    lib = _lib.load()
+    for n in (8, 9, 10, 37):
+        env = synth.make_env_cube(np.random.default_rng(n), n)
+        tiles = P.tile_env_footprints(P.to_device_f16(env, gpu))
+        k = n // 3 + 1
+        assert tiles.numel() == lib.vkr_env_footprint_tiles_bytes(n) == 6 * k * k * 128
+        got = tiles.cpu().numpy().view(np.uint16).reshape(6, k, k, 4, 4, 4)   # face, m, k, row, column, channel
+        for f in range(6):
+            for m in range(k):
+                for kk in range(k):
+                    for r in range(4):
+                        for c in range(4):
+                            i, j = 3 * kk + c - 1, 3 * m + r - 1
+                            want = np.zeros(4, np.uint16)
+                            if i <= n and j <= n:
+                                ok, (of, oi, oj) = oracle.cube_fold(n, f, i, j)
+                                if ok:
+                                    want = env[of, oj, oi]
+                            assert np.array_equal(got[f, m, kk, r, c], want), (n, f, m, kk, r, c)
+    assert lib.vkr_env_footprint_tiles_bytes(0) == -1 and lib.vkr_env_footprint_tiles_bytes(8193) == -1
+
+
+def test_irradiance_by_region_rows_of_a_large_environment(gpu, oracle):
+    """The by-region order with row sums where a face has several regions (520^2 faces: 2 x 2 regions of 87 cells;
+    1024^2: 3 x 3 of 114), rows of one rank, a workspace that is reused, too small or missing, the word that counts
+    texels with samples unaccounted for, cube corners and face edges (small cubes look across them all the time)."""
+    torch, P = _torch(), _passes()
+    lib = _lib.load()
+    for env_n, n in ((1024, 4), (520, 3), (640, 5), (16, 6)):
+        env = synth.make_env_cube(np.random.default_rng(env_n + n), env_n)
+        dev_env = P.to_device_f16(env, gpu)
+        tiles = P.tile_env_footprints(dev_env)
+        want = oracle.irradiance(env, n, 3)
+        out = torch.zeros((6, n, n, 4), dtype=torch.float16, device=gpu)
+        ws = P.irradiance_by_region_rows(tiles, env_n, out)
+        assert P.irradiance_uncovered(ws) == 0
+        assert_bits_equal(P.f16_bits(out), want, f"irradiance by region with row sums, environment {env_n}, cube {n}")
+        seq = oracle.f16_to_f32(oracle.irradiance(env, n, 0))
+        got = out.float().cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(seq))   # odd n: the centre texels of the +-Y faces have no frame
+        assert (np.isnan(seq) | (np.abs(got - seq) <= 1.0 * f16_ulp(seq))).all()
+        r0, r1 = n + 1, 4 * n - 1
+        part = torch.full((6, n, n, 4), 7.0, dtype=torch.float16, device=gpu)
+        P.irradiance_by_region_rows(tiles, env_n, part, (r0, r1), workspace=ws)
+        need = lib.vkr_ibl_irradiance_by_region_rows_workspace_bytes(env_n, n, r0, r1)
+        assert 0 < need <= ws.numel() and P.irradiance_uncovered(ws, need) == 0
+        got = P.f16_bits(part).reshape(6 * n, n, 4)
+        assert np.array_equal(got[r0:r1], want.reshape(6 * n, n, 4)[r0:r1])
+        assert (part.view(6 * n, n, 4)[:r0] == 7.0).all() and (part.view(6 * n, n, 4)[r1:] == 7.0).all()
+        with pytest.raises(_lib.VkrError):
+            P.irradiance_by_region_rows(tiles, env_n, out, workspace=ws[:need - 1])
+        # the convenience form: tiles and workspace made inside, the sample count checked
+        again = torch.zeros_like(out)
+        P.irradiance(dev_env, again, _lib.IRRADIANCE_FASTEST)
+        assert torch.equal(again, out)
+    # more shapes of regions and texel grids, against the kernel in the shader's order: every sample accounted for, and
+    # the two sums within rounding of each other
+    for env_n, n in ((1536, 8), (4096, 6), (512, 16), (2048, 9), (72, 5), (383, 7), (385, 4), (1, 2), (5, 1)):
+        gen = torch.Generator(device=gpu).manual_seed(env_n)
+        dev_env = (torch.rand((6, env_n, env_n, 4), generator=gen, device=gpu) * 4.0).to(torch.float16)  # made on the device: 4096^2 faces are 0.8 GB
+        out = torch.zeros((6, n, n, 4), dtype=torch.float16, device=gpu)
+        seq = torch.zeros_like(out)
+        ws = P.irradiance_by_region_rows(P.tile_env_footprints(dev_env), env_n, out)
+        P.irradiance(dev_env, seq, 0)
+        assert P.irradiance_uncovered(ws) == 0, (env_n, n)
+        a, b = seq.float().cpu().numpy(), out.float().cpu().numpy()
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        assert (np.isnan(a) | (np.abs(a - b) <= 1.0 * f16_ulp(a))).all(), (env_n, n)
+        del dev_env, ws
+    assert lib.vkr_ibl_irradiance_by_region_rows_workspace_bytes(0, 4, 0, 24) == -1
+    assert lib.vkr_ibl_irradiance_by_region_rows_workspace_bytes(64, 4, 0, 25) == -1
+    env = P.to_device_f16(synth.make_env_cube(np.random.default_rng(1), 16), gpu)
+    empty = torch.zeros((6, 3, 3, 4), dtype=torch.float16, device=gpu)
+    P.irradiance_by_region_rows(P.tile_env_footprints(env), 16, empty, (5, 5))  # no rows: nothing is written
     assert (empty == 0).all()
 
 
@@ -527,6 +609,18 @@ def test_render_stages_record_and_submit_like_the_reference(gpu, oracle):
         assert (r.Read(_lib.TARGET_BLOOM2, cf)[..., :3] == 0).all()
         want_ldr = oracle.postprocess(np.ascontiguousarray(r.Read(_lib.TARGET_COLOR, cf)), np.ascontiguousarray(r.Read(_lib.TARGET_BLOOM2, cf)))
         assert np.abs(r.Read(_lib.TARGET_LDR, cf).astype(np.int32) - want_ldr.astype(np.int32)).max() <= 1
+
+        # a host that mirrors EndFrame literally calls Draw() in every stage: with no DrawModel calls in the frame the
+        # geometry and shadow passes hold zero draws and clear (VulkanRenderer.cs:357-366, 391-400, 417-424), whatever
+        # was uploaded -- the frame is the skybox alone
+        cf = r.CurrentFrame
+        r.BeginFrame()
+        upload()
+        for stage in range(_lib.STAGE_COUNT):
+            record(stage, cf)
+        r.SubmitFrame()
+        assert_bits_equal(r.Read(_lib.TARGET_COLOR, cf)[..., :3], sky[..., :3], "Draw() without draw calls clears the G-buffer")
+        assert (r.Read(_lib.TARGET_THRESHOLD, cf)[..., :3] == 0).all()
 
 
 def test_strip_pair_with_local_halo_copy_matches_whole_frame(gpu, oracle):

@@ -40,9 +40,10 @@ class OracleIblBackend:
     def sampling_copy(self, env):
         return env, 0
 
-    def irradiance(self, env, out, rows, env_layout=0):
+    def irradiance(self, env, out, rows, env_layout=0, order=0, linear=None):
         from tests import oracle
-        self._rows(out, oracle.irradiance(self._bits(env), out.shape[1], 0), rows)
+        order = 3 if order == -1 else order   # IRRADIANCE_FASTEST is the by-region order with row sums
+        self._rows(out, oracle.irradiance(self._bits(env), out.shape[1], order), rows)
 
     def prefilter(self, env, out, roughness, rows, env_layout=0):
         from tests import oracle
@@ -79,7 +80,8 @@ def _free_port():
 def test_sharded_ibl_equals_the_single_device_images(world, tmp_path, oracle):
     src = _source().numpy().view(np.uint16)
     env = oracle.equirect_to_cube(src, CFG.env_res)
-    want = {"irradiance": oracle.irradiance(env, CFG.irradiance_res, 0), "brdf_lut": oracle.brdf_lut(CFG.lut_res)}
+    want = {"irradiance": oracle.irradiance(env, CFG.irradiance_res, 3),  # IblConfig's default order
+             "brdf_lut": oracle.brdf_lut(CFG.lut_res)}
     for m in range(CFG.prefilter_mips):
         want[f"prefilter{m}"] = oracle.prefilter(env, CFG.prefilter_res >> m, m / (CFG.prefilter_mips - 1))
     out_path = str(tmp_path / "ibl")

@@ -102,7 +102,7 @@ def test_aces_and_gamma(oracle):
 def test_irradiance_of_constant_environment(oracle):
     # irradiance.frag:21-36: 252 x 63 samples; PI * c * mean(cos*sin) = 0.99708 c
     env = const_cube(8, (0.5, 1.0, 2.0))
-    for order in (0, 1, 2):
+    for order in (0, 1, 2, 3):
         out = oracle.f16_to_f32(oracle.irradiance(env, 2, order))
         assert np.allclose(out[..., :3], np.array([0.5, 1.0, 2.0]) * 0.99708, rtol=2e-3)
         assert (out[..., 3] == 1.0).all()
@@ -115,12 +115,34 @@ def test_irradiance_orders_agree_to_rounding(oracle):
     assert np.allclose(a, b, rtol=2e-3, atol=1e-4)
     c = oracle.f16_to_f32(oracle.irradiance(env, 2, 2))
     assert np.allclose(a, c, rtol=2e-3, atol=1e-4)
+    d = oracle.f16_to_f32(oracle.irradiance(env, 2, 3))
+    assert np.allclose(a, d, rtol=2e-3, atol=1e-4)
     # faces of several regions each (order 2 groups the samples by 512 x 512-texel region; 520^2: regions of 512 and 8)
     env = synth.make_env_cube(np.random.default_rng(3), 520)
     a = oracle.f16_to_f32(oracle.irradiance(env, 1, 0))
     c = oracle.f16_to_f32(oracle.irradiance(env, 1, 2))
     assert np.isnan(a[2:4, ..., :3]).all()   # N = (0, +-1, 0): cross(up, N) = 0, the shader's frame is NaN
     assert np.allclose(a, c, rtol=1e-3, atol=1e-4, equal_nan=True)
+    # order 3 cuts a 520^2 face into 2 x 2 regions of 87 cells of 3 x 3 footprint positions (174 cells a side)
+    d = oracle.f16_to_f32(oracle.irradiance(env, 1, 3))
+    assert np.allclose(a, d, rtol=1e-3, atol=1e-4, equal_nan=True)
+
+
+def test_region_grid_of_the_rows_order(oracle):
+    """cube_lookup_region3: footprint base texels shifted into [0, n], cells of 3, regions of at most 128 cells a side."""
+    import ctypes as C
+    lib = oracle.load()
+    lib.orc_cube_lookup_region3.restype = C.c_int
+    def region(n, d):
+        v = (C.c_float * 3)(*d)
+        return lib.orc_cube_lookup_region3(n, v)
+    # 2048: 683 cells, 6 regions of 114 cells (342 texel positions) a side
+    assert region(2048, (1.0, 0.0, 0.0)) % 6 == 0 and region(2048, (-1.0, 0.0, 0.0)) % 6 == 1
+    centre = region(2048, (0.001, 0.002, 1.0))      # face +Z just off the centre: x = 1024.5 -> I0 = 1025 -> cell 341 -> column 2
+    assert centre % 6 == 4 and (centre // 6) % 6 == 2 and (centre // 6) // 6 in (2, 3)
+    corner = region(2048, (-0.99999, 0.99999, 1.0))  # top-left corner of +Z: I0 = 0 or 1, J0 = 0 or 1
+    assert corner == 4
+    assert region(64, (0.3, -0.2, -1.0)) == 5        # small faces are one region
 
 
 def test_prefilter_of_constant_environment_and_mip0(oracle):

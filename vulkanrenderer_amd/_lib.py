@@ -13,15 +13,17 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VKR_HIP_LIB") or os.path.join(_HERE, "libvkr_hip.so")
 
 VKR_OK = 0
+ABI_VERSION = 3  # VKR_ABI_VERSION of include/vkr_hip.h as this binding was written against
 VKR_ERR_INVALID, VKR_ERR_HIP, VKR_ERR_UNSUPPORTED, VKR_ERR_ORDER, VKR_ERR_NO_DEVICE = -1, -2, -3, -4, -5
 COVERAGE_FULLSCREEN, COVERAGE_MESH = 0, 1
 CUBE_LAYOUT_LINEAR, CUBE_LAYOUT_TILED_8X4, CUBE_LAYOUT_TILED_8X4_X25 = 0, 1, 2
-ENV_LAYOUT_LINEAR, ENV_LAYOUT_TILED_4X4 = 0, 1
+ENV_LAYOUT_LINEAR, ENV_LAYOUT_TILED_4X4, ENV_LAYOUT_FOOTPRINT_TILES = 0, 1, 2
 WRAP_REPEAT, WRAP_CLAMP = 0, 1
 SRC_RGBA8_SRGB, SRC_RGBA16F = 0, 1
 POST_SRGB_TARGET = 1
 GBUFFER_STATIC_MAX_PIXELS, GBUFFER_STATIC_MAX_DRAWS = 2097152, 64
-IRRADIANCE_SEQUENTIAL, IRRADIANCE_PHI_SLICES, IRRADIANCE_BY_REGION = 0, 1, 2
+IRRADIANCE_SEQUENTIAL, IRRADIANCE_PHI_SLICES, IRRADIANCE_BY_REGION, IRRADIANCE_BY_REGION_ROWS = 0, 1, 2, 3
+IRRADIANCE_FASTEST = -1
 (TARGET_COLOR, TARGET_THRESHOLD, TARGET_BLOOM1, TARGET_BLOOM2, TARGET_LDR,
  TARGET_ENV, TARGET_IRRADIANCE, TARGET_PREFILTER, TARGET_BRDF_LUT) = range(9)
 (STAGE_POINT_SHADOW, STAGE_GEOMETRY, STAGE_DIR_SHADOW, STAGE_COMPOSITION, STAGE_BLOOM1, STAGE_BLOOM2, STAGE_POSTPROCESS) = range(7)
@@ -162,6 +164,10 @@ PROTOTYPES = {
     "vkr_ibl_irradiance": [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp],
     "vkr_ibl_irradiance_by_region": [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, C.c_int64, _vp],
     "vkr_ibl_irradiance_by_region_workspace_bytes": [_i32, _i32, _i32, _i32],
+    "vkr_env_footprint_tiles_bytes": [_i32],
+    "vkr_tile_rgba16f_footprints": [_vp, _vp, _i32, _vp],
+    "vkr_ibl_irradiance_by_region_rows": [_vp, _i32, _vp, _i32, _i32, _i32, _vp, C.c_int64, _vp],
+    "vkr_ibl_irradiance_by_region_rows_workspace_bytes": [_i32, _i32, _i32, _i32],
     "vkr_ibl_prefilter": [_vp, _i32, _i32, _vp, _i32, _f, _i32, _i32, _vp],
     "vkr_tile_rgba16f_faces": [_vp, _vp, _i32, _i32, _vp],
     "vkr_measure_peaks": [C.POINTER(C.c_float), C.POINTER(C.c_float)],
@@ -213,7 +219,8 @@ PROTOTYPES = {
 _lib = None
 
 
-RETURNS_INT64 = {"vkr_gbuffer_workspace_bytes", "vkr_ibl_irradiance_by_region_workspace_bytes"}
+RETURNS_INT64 = {"vkr_gbuffer_workspace_bytes", "vkr_ibl_irradiance_by_region_workspace_bytes",
+                 "vkr_ibl_irradiance_by_region_rows_workspace_bytes", "vkr_env_footprint_tiles_bytes"}
 
 
 def load() -> C.CDLL:
@@ -231,6 +238,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.restype = C.c_int64 if name in RETURNS_INT64 else C.c_int32
         fn.argtypes = argtypes
+    if lib.vkr_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has interface version {lib.vkr_abi_version()}, this binding needs {ABI_VERSION}: rebuild the library")
     _lib = lib
     return lib
 

@@ -344,7 +344,7 @@ static VkrBloomArgs bloom_args(vkr_ctx *c, Frame &f, int horizontal)
 using namespace vkr;
 
 extern "C" const char *vkr_last_error(void) { return g_error; }
-extern "C" int32_t vkr_abi_version(void) { return 1; }
+extern "C" int32_t vkr_abi_version(void) { return VKR_ABI_VERSION; }
 
 extern "C" int32_t vkr_device_count(void)
 {
@@ -903,9 +903,11 @@ static int32_t run_stage(vkr_ctx *c, Frame &f, int32_t stage)
 {
     int32_t rc;
     switch (stage) {
-    case VKR_STAGE_POINT_SHADOW: return run_point_shadows(c, f);
-    case VKR_STAGE_GEOMETRY: return run_geometry_pass(c, f);
-    case VKR_STAGE_DIR_SHADOW: return run_dir_shadow(c, f);
+    // A frame without draw calls records zero vkCmdDraw calls into these three passes (their loops over
+    // solidModelDrawCalls are empty, VulkanRenderer.cs:357-366, 391-400, 417-424): begun and ended, they clear.
+    case VKR_STAGE_POINT_SHADOW: return c->draw_calls.empty() ? clear_stage_attachments(c, f, stage) : run_point_shadows(c, f);
+    case VKR_STAGE_GEOMETRY: return c->draw_calls.empty() ? clear_stage_attachments(c, f, stage) : run_geometry_pass(c, f);
+    case VKR_STAGE_DIR_SHADOW: return c->draw_calls.empty() ? clear_stage_attachments(c, f, stage) : run_dir_shadow(c, f);
     case VKR_STAGE_COMPOSITION: {  // skybox draw, composition draw, one light-volume draw per light
         VkrShadeArgs a;
         if ((rc = fill_shade_args(c, f, a)) != VKR_OK) return rc;

@@ -8,6 +8,7 @@
 #include <mutex>
 #include "vkr_device.h"
 #include "vkr_host.h"
+#include "vkr_irr_bounds.h"
 
 namespace vkr {
 
@@ -239,8 +240,6 @@ __global__ __launch_bounds__(256) void irradiance_slices_kernel(const void *env,
 static constexpr int IRR_GROUP = 64;         // output texels per workgroup
 static constexpr int IRR_QUEUE = 128;        // entries of a wave's queue of samples to fetch (a ring; at most 63 + 64 are held)
 static constexpr int IRR_REGION_SHIFT = 9;   // regions of 512 x 512 texels
-static constexpr float IRR_STEP = 0.025f;    // irradiance.frag:19, sampleDelta
-static constexpr float IRR_MARGIN = 0.004f;  // radians by which a region's bounds are widened
 
 // r in the coordinates of face f: (sc, tc) as cube_face gives them on that face, and the major axis signed so that it
 // is positive on the face
@@ -312,8 +311,6 @@ VKR_DEV f3 fetch_footprint_on_face(const void *cube, int n, int face, int i0, in
                fma_(w3, tx[3].g, fma_(w2, tx[2].g, fma_(w1, tx[1].g, w0 * tx[0].g))),
                fma_(w3, tx[3].b, fma_(w2, tx[2].b, fma_(w1, tx[1].b, w0 * tx[0].b))));
 }
-
-struct irr_box { int a0, na, b0, nb; };  // phi indices a0 .. a0+na-1 (mod nphi), theta indices b0 .. b0+nb-1
 
 // partial: [region][4][texels_padded] -- red, green, blue sums and the number of samples, texels_padded = n_groups * IRR_GROUP
 template <bool TILED>
@@ -550,9 +547,262 @@ __global__ __launch_bounds__(256) void irradiance_regions_sum_kernel(const float
         r += p[0]; g += p[padded]; b += p[2 * padded]; found += p[3 * padded];
     }
     const int count = nphi * ntheta;
-    if (found != (float)count) atomicAdd(uncovered, 1u);
+    if (found != (float)count) {  // a caller that never looks at the count still cannot take the texel for a result
+        atomicAdd(uncovered, 1u);
+        r = g = b = __builtin_nanf("");
+    }
     const float inv_count = rcp_rn((float)count);
     out[(size_t)row_begin * n + texel] = pack4((PI_F * r) * inv_count, (PI_F * g) * inv_count, (PI_F * b) * inv_count, 1.0f);
+}
+
+// ---- irradiance.frag:10-39, summed by region of the environment and by phi row -------------------------------
+//
+// The arrangement of irradiance_region_kernel with two changes that come from where its time went: finding the samples
+// of a (texel, region) pair cost more vector instructions than fetching them, and the fetches sat on the rate at which
+// an XCD's L2 hands out cache lines (1.5 lines per sample from 4x4-texel tiles, four load instructions per sample).
+//
+// (1) The environment is read from "footprint tiles": 4x4-texel tiles of 128 bytes laid at a stride of THREE texels in
+// both directions over each face extended by a one-texel apron (the neighbouring faces' texels, as seamless filtering
+// folds them).  The 2x2 footprint of a lookup with base texel (i0, j0) then lies in tile ((i0+1)/3, (j0+1)/3), whole:
+// one cache line and two 16-byte loads per sample, no edge case except the eight corners of the cube.
+//
+// (2) A lane takes a phi ROW of a pair, not a cell of its (phi, theta) box: the theta indices of the row that can land
+// in the region follow from the four planes that bound it (irr_row_interval), 1.05 cells per sample found against 1.8
+// for the box, and the lane walks them with the sample's own arithmetic, adding what lands in the region to ITS sum --
+// no queue, no compaction, and the summation order needs none: within a pair every phi row is summed on its own
+// (theta ascending), the row sums are added in phi order, the pair sums in region order (order = 3 of the oracle's
+// orc_irradiance).  The rows of a workgroup's pairs are sorted by interval length first, so that the lanes of a wave
+// finish together.
+static constexpr int IRR_ROWS_LDS = 1024;  // row sums a workgroup holds at a time (a texel's rows, at most IRR_MAX_PHI, always fit)
+static constexpr int IRR_LEN_BINS = 64;    // interval lengths 0 .. 63 (at most IRR_MAX_THETA - 1)
+
+// Bytes of an n^2-face cube in footprint tiles, and the tile arithmetic (shared by the re-layout kernel and the lookups)
+VKR_DEV unsigned div3(unsigned v) { return (v * 43691u) >> 17; }  // exact below 98 304
+static inline int64_t footprint_tiles_per_side(int n) { return n / 3 + 1; }
+
+// The cube in footprint tiles.  One lane writes one row of a tile (four texels, 32 bytes); tile (k, m) of a face holds
+// the texels (3k - 1 .. 3k + 2) x (3m - 1 .. 3m + 2) of the face, those beyond an edge taken from the neighbouring
+// face, those beyond a corner of the cube or beyond the apron zero (never read: see fetch_footprint_tile).
+__global__ __launch_bounds__(256) void footprint_tiles_kernel(const uint2 *src, uint4 *dst, int n, unsigned tiles_per_side, unsigned total_rows)
+{
+    const unsigned g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= total_rows) return;
+    const unsigned t = g >> 2, row = g & 3u;
+    const unsigned per_face = tiles_per_side * tiles_per_side;
+    const unsigned f = t / per_face, tf = t - f * per_face;
+    const unsigned m = tf / tiles_per_side, k = tf - m * tiles_per_side;
+    const int j = (int)(3u * m + row) - 1, i0 = (int)(3u * k) - 1;
+    uint2 tx[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int i = i0 + c;
+        tx[c] = make_uint2(0u, 0u);
+        if (i <= n && j <= n) {
+            int of, oi, oj;
+            if (cube_fold(n, (int)f, i, j, of, oi, oj)) tx[c] = src[((size_t)of * n + oj) * n + oi];
+        }
+    }
+    dst[(size_t)g * 2u] = make_uint4(tx[0].x, tx[0].y, tx[1].x, tx[1].y);
+    dst[(size_t)g * 2u + 1u] = make_uint4(tx[2].x, tx[2].y, tx[3].x, tx[3].y);
+}
+
+typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+
+// LINEAR lookup at the unrounded texel coordinates (x, y) = (s n - 1/2, t n - 1/2) of a face stored in footprint tiles
+// (`face` points at the face's first tile): the arithmetic of texcube_fetch_footprint, the four texels from one tile.
+VKR_DEV f3 fetch_footprint_tile(const char *face, int n, unsigned tiles_per_side, float x, float y)
+{
+    const float fx = __builtin_floorf(x), fy = __builtin_floorf(y);
+    const float al = x - fx, be = y - fy;
+    const unsigned I0 = (unsigned)((int)fx + 1), J0 = (unsigned)((int)fy + 1);  // in [0, n]
+    const unsigned k = div3(I0), m = div3(J0);
+    const unsigned at = ((m * tiles_per_side + k) << 7) + ((((J0 - 3u * m) << 2) + (I0 - 3u * k)) << 3);
+    const u32x4_a8 r0 = *(const u32x4_a8 *)(face + at), r1 = *(const u32x4_a8 *)(face + at + 32u);
+    rgba tx[4] = {unpack4(make_uint2(r0.x, r0.y)), unpack4(make_uint2(r0.z, r0.w)), unpack4(make_uint2(r1.x, r1.y)), unpack4(make_uint2(r1.z, r1.w))};
+    const bool x_edge = I0 == 0u || I0 == (unsigned)n, y_edge = J0 == 0u || J0 == (unsigned)n;
+    if (__builtin_expect(x_edge && y_edge, 0)) {  // cube corner: the texel beyond both edges is the mean of the other three
+        const unsigned missing = (I0 == 0u ? 0u : 1u) | (J0 == 0u ? 0u : 2u);
+        float sr = 0.0f, sg = 0.0f, sb = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; q++) if ((unsigned)q != missing) { sr += tx[q].r; sg += tx[q].g; sb += tx[q].b; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) if ((unsigned)q == missing) { tx[q].r = sr * (1.0f / 3.0f); tx[q].g = sg * (1.0f / 3.0f); tx[q].b = sb * (1.0f / 3.0f); }
+    }
+    const float w0 = (1.0f - al) * (1.0f - be), w1 = al * (1.0f - be), w2 = (1.0f - al) * be, w3 = al * be;
+    return mk3(fma_(w3, tx[3].r, fma_(w2, tx[2].r, fma_(w1, tx[1].r, w0 * tx[0].r))),
+               fma_(w3, tx[3].g, fma_(w2, tx[2].g, fma_(w1, tx[1].g, w0 * tx[0].g))),
+               fma_(w3, tx[3].b, fma_(w2, tx[2].b, fma_(w1, tx[1].b, w0 * tx[0].b))));
+}
+
+// partial: [region][4][texels_padded] as for irradiance_region_kernel; irradiance_regions_sum_kernel adds the regions
+__global__ __launch_bounds__(256) void irradiance_rows_kernel(const char *env, int env_n, unsigned tiles_per_side, int n, int nphi, int ntheta, int row_begin, int n_texels,
+                                                              float *partial, int regions_per_side, int cells_per_region, int n_regions, int n_groups)
+{
+    __shared__ float2 phi_cs[IRR_MAX_PHI], theta_sc[IRR_MAX_THETA];
+    __shared__ float frame[IRR_GROUP][9];
+    __shared__ irr_box box[IRR_GROUP];
+    __shared__ int row_base[IRR_GROUP + 1];
+    __shared__ float4 row_sum[IRR_ROWS_LDS];      // red, green, blue, samples of a row
+    __shared__ uint32_t row_rec[IRR_ROWS_LDS];    // texel | phi index << 6 | first theta << 14 | last theta << 20
+    __shared__ uint16_t row_order[IRR_ROWS_LDS];  // rows by falling interval length
+    __shared__ uint32_t len_count[IRR_LEN_BINS], len_base[IRR_LEN_BINS];
+    __shared__ float4 pair_sum[IRR_GROUP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    // workgroups go to the XCDs round-robin by id: XCD x works through regions x, x + 8, ... one after the other
+    const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
+    const int turn = (kk / n_groups) * 8 + xcd, group = kk % n_groups;
+    if (turn >= n_regions) return;
+    int region = turn;  // the four mirror images of a region on the six faces weigh the same: every XCD gets three of each
+    if ((regions_per_side & 1) == 0) {
+        const int half = regions_per_side >> 1, quad = turn / 24, image = turn % 24, mirror = image / 6;
+        const int qx = quad % half, qy = quad / half;
+        const int cx = (mirror & 1) ? regions_per_side - 1 - qx : qx, cy = (mirror & 2) ? regions_per_side - 1 - qy : qy;
+        region = (cy * regions_per_side + cx) * 6 + image % 6;
+    }
+    const int rf = region % 6, cell = region / 6;
+    const int rx = cell % regions_per_side, ry = cell / regions_per_side;
+    const irr_region_rect geo = irr_region_geometry(env_n, regions_per_side, cells_per_region, rx, ry);
+    const bool sc_later = (rf >> 1) >= 1;  // sc is x on the y and z faces, z on the x faces
+    const bool tc_later = (rf >> 1) == 2;  // tc is y on the z faces, z or y (looked at earlier) on the others
+    const bool positive = (rf & 1) == 0;
+    const char *face = env + (size_t)rf * tiles_per_side * tiles_per_side * 128u;
+    for (int t = tid; t < nphi; t += 256) phi_cs[t] = g_irr_phi_cs[t];
+    if (tid < ntheta) theta_sc[tid] = g_irr_theta_sc[tid];
+    if (tid < IRR_LEN_BINS) len_count[tid] = 0u;
+    if (tid < IRR_GROUP) {
+        const int idx = min(group * IRR_GROUP + tid, n_texels - 1);
+        const int row = row_begin + idx / n, i = idx % n;
+        const int f = row / n, j = row - f * n;
+        const f3 N = normalize3(face_dir(f, i, j, n));
+        const f3 right = normalize3(mk3(N.z, 0.0f, -N.x));  // normalize(cross((0,1,0), N))
+        const f3 up = normalize3(cross3(N, right));
+        const irr_v3 Nf = irr_to_face_axes(rf, irr_mk(N.x, N.y, N.z)), rightf = irr_to_face_axes(rf, irr_mk(right.x, right.y, right.z)),
+                     upf = irr_to_face_axes(rf, irr_mk(up.x, up.y, up.z));
+        float *fr = frame[tid];
+        fr[0] = Nf.x; fr[1] = Nf.y; fr[2] = Nf.z; fr[3] = rightf.x; fr[4] = rightf.y; fr[5] = rightf.z; fr[6] = upf.x; fr[7] = upf.y; fr[8] = upf.z;
+        irr_box bx; bx.a0 = 0; bx.na = 0; bx.b0 = 0; bx.nb = 0;
+        // N = (0, +-1, 0) has no tangent frame (right = normalize(0) is NaN, as in the shader): every sample direction
+        // is then NaN, which the lookup takes to texel (0, 0) of face 1 -- region 1 -- with NaN weights
+        const float frame_sum = ((right.x + right.y) + right.z) + ((up.x + up.y) + up.z);
+        if (group * IRR_GROUP + tid < n_texels) {
+            if (!(frame_sum == frame_sum)) {
+                if (region == 1) { bx.na = nphi; bx.nb = ntheta; bx.a0 = -1; }  // a0 = -1 marks it
+            } else bx = irr_pair_box(Nf, rightf, upf, geo.u0, geo.u1, geo.v0, geo.v1, 4.0f / (float)env_n, nphi, ntheta);
+        }
+        box[tid] = bx;
+        int incl = bx.na;  // rows of the texels before this one
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+        row_base[tid + 1] = incl;
+        if (tid == 0) row_base[0] = 0;
+        pair_sum[tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    __syncthreads();
+    const float nf = (float)env_n;
+    for (int t0 = 0; t0 < IRR_GROUP;) {
+        // the texels [t0, t1) whose rows fit the row buffer together
+        int t1 = IRR_GROUP;
+        if (row_base[IRR_GROUP] - row_base[t0] > IRR_ROWS_LDS) {
+            int lo = t0 + 1, hi = IRR_GROUP;  // row_base[lo] - row_base[t0] fits, row_base[hi] - .. does not
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (row_base[mid] - row_base[t0] <= IRR_ROWS_LDS) lo = mid; else hi = mid; }
+            t1 = lo;
+        }
+        const int base = row_base[t0], rows = row_base[t1] - base;
+        // every row: its texel, its phi index, the theta interval that can land in the region; counted by interval length
+        for (int q = tid; q < rows; q += 256) {
+            const int g = base + q;
+            int lo = t0, hi = t1;  // row_base[lo] <= g < row_base[hi]
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (row_base[mid] <= g) lo = mid; else hi = mid; }
+            const int t = lo, r = g - row_base[t];
+            const irr_box bx = box[t];
+            const int a0 = max(bx.a0, 0), wrapped = max(a0 + bx.na - nphi, 0);  // a box that runs over the end of the phi range: the part that wrapped comes first
+            const int a = r < wrapped ? r : a0 + (r - wrapped);
+            int bl = bx.b0, bh = bx.b0 + bx.nb - 1;
+            if (bx.a0 >= 0) {
+                const float *fr = frame[t];
+                const float2 pcs = phi_cs[a];
+                int il, ih;
+                irr_row_interval(irr_mk(fr[0], fr[1], fr[2]), irr_mk(fr[3], fr[4], fr[5]), irr_mk(fr[6], fr[7], fr[8]), pcs.x, pcs.y, geo.U0, geo.U1, geo.V0, geo.V1, &il, &ih);
+                bl = max(bl, il); bh = min(bh, ih);
+            }
+            const int len = max(bh - bl + 1, 0);
+            if (len == 0) { bl = 1; bh = 0; row_sum[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+            row_rec[q] = (uint32_t)t | ((uint32_t)a << 6) | ((uint32_t)bl << 14) | ((uint32_t)bh << 20);
+            atomicAdd(&len_count[len], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {  // longest rows first; rows without an interval are left out
+            const uint32_t c = tid == 0 ? 0u : len_count[IRR_LEN_BINS - tid];  // lane k: length 64 - k
+            uint32_t incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+            if (tid > 0) len_base[IRR_LEN_BINS - tid] = incl - c;
+            if (tid == 63) len_base[0] = incl;  // = the number of rows with an interval
+        }
+        __syncthreads();
+        for (int q = tid; q < rows; q += 256) {
+            const uint32_t rec = row_rec[q];
+            const int len = max((int)((rec >> 20) & 63u) - (int)((rec >> 14) & 63u) + 1, 0);
+            if (len > 0) row_order[atomicAdd(&len_base[len], 1u)] = (uint16_t)q;
+        }
+        __syncthreads();
+        const int busy = (int)len_base[0];
+        // a lane walks its row's interval: every cell decided exactly, what lands in the region added to the row's sum
+        for (int s = tid; s < busy; s += 256) {
+            const int q = row_order[s];
+            const uint32_t rec = row_rec[q];
+            const int t = (int)(rec & 63u), a = (int)((rec >> 6) & 255u), bl = (int)((rec >> 14) & 63u), bh = (int)((rec >> 20) & 63u);
+            const bool every = box[t].a0 < 0;  // a texel without a frame: all of its samples land here
+            const float *fr = frame[t];
+            const f3 N = mk3(fr[0], fr[1], fr[2]), right = mk3(fr[3], fr[4], fr[5]), up = mk3(fr[6], fr[7], fr[8]);
+            const float2 pcs = phi_cs[a];
+            float sr = 0.0f, sg = 0.0f, sb = 0.0f;
+            int found = 0;
+            for (int b = bl; b <= bh; b++) {
+                const float2 tsc = theta_sc[b];
+                const float st = tsc.x, ct = tsc.y;
+                const float tx = st * pcs.x, ty = st * pcs.y, tz = ct;
+                // the direction in the face's coordinates; it lies on the face when cube_face would pick it (ties: z over y over x)
+                const float sc = fma_(tz, N.x, fma_(ty, up.x, tx * right.x));
+                const float tc = fma_(tz, N.y, fma_(ty, up.y, tx * right.y));
+                const float mj = fma_(tz, N.z, fma_(ty, up.z, tx * right.z));
+                const float asc = __builtin_fabsf(sc), atc = __builtin_fabsf(tc), ma = __builtin_fabsf(mj);
+                // the major axis wins a tie against an axis that cube_face looks at later (z, then y, then x) and loses it
+                // against one it looks at earlier
+                const bool over_s = sc_later ? ma >= asc : !(asc >= ma);
+                const bool over_t = tc_later ? ma >= atc : !(atc >= ma);
+                const bool side = positive ? mj >= 0.0f : !(mj <= 0.0f);
+                const float ima = rcp_rn_checked(ma);
+                const float s_ = fma_(sc * ima, 0.5f, 0.5f), t_ = fma_(tc * ima, 0.5f, 0.5f);
+                const float x = s_ * nf - 0.5f, y = t_ * nf - 0.5f;
+                const bool inside = x >= geo.x_lo && x < geo.x_hi && y >= geo.y_lo && y < geo.y_hi;
+                if ((over_s && over_t && side && inside) || every) {
+                    const f3 c = fetch_footprint_tile(face, env_n, tiles_per_side, x, y);
+                    sr = fma_(c.x * ct, st, sr);
+                    sg = fma_(c.y * ct, st, sg);
+                    sb = fma_(c.z * ct, st, sb);
+                    found++;
+                }
+            }
+            row_sum[q] = make_float4(sr, sg, sb, (float)found);
+        }
+        __syncthreads();
+        {   // the rows of a pair in phi order, one lane per texel and channel (the fourth: the number of samples)
+            const int t = t0 + (tid >> 2), ch = tid & 3;
+            if (t < t1) {
+                const float *rs = (const float *)row_sum + ch;
+                float acc = 0.0f;
+                for (int q = row_base[t] - base, e = row_base[t + 1] - base; q < e; q++) acc += rs[4 * q];
+                ((float *)&pair_sum[t])[ch] = acc;
+            }
+            if (tid < IRR_LEN_BINS) len_count[tid] = 0u;
+        }
+        __syncthreads();
+        t0 = t1;
+    }
+    const size_t padded = (size_t)n_groups * IRR_GROUP;
+    const int w = tid >> 6;
+    partial[((size_t)region * 4 + w) * padded + (size_t)group * IRR_GROUP + lane] = ((const float *)&pair_sum[lane])[w];
 }
 
 // ---- prefilter.frag / brdf.frag shared pieces -----------------------------------------------
@@ -867,6 +1117,79 @@ extern "C" int32_t vkr_ibl_irradiance_by_region(const void *env, int32_t env_n, 
     hipLaunchKernelGGL(irradiance_regions_sum_kernel, dim3((n_texels + 255) / 256), dim3(256), 0, s,
                        partial, n_regions, n_groups, (uint2 *)out, n, g_irr_nphi, g_irr_ntheta, row_begin, n_texels, uncovered);
     return launch_status("vkr_ibl_irradiance_by_region");
+}
+
+extern "C" int64_t vkr_env_footprint_tiles_bytes(int32_t n)
+{
+    using namespace vkr;
+    if (n <= 0 || n > 8192) { fail(VKR_ERR_INVALID, "vkr_env_footprint_tiles_bytes: face size %d outside [1, 8192]", n); return -1; }
+    const int64_t k = footprint_tiles_per_side(n);
+    return 6 * k * k * 128;
+}
+
+extern "C" int32_t vkr_tile_rgba16f_footprints(const void *linear, void *tiles, int32_t n, void *stream)
+{
+    using namespace vkr;
+    VKR_REQUIRE(linear && tiles, "vkr_tile_rgba16f_footprints: an image is null");
+    VKR_REQUIRE(n > 0 && n <= 8192, "vkr_tile_rgba16f_footprints: face size %d outside [1, 8192]", n);
+    const int64_t k = footprint_tiles_per_side(n), rows = 6 * k * k * 4;  // one lane per tile row
+    const char *a = (const char *)linear, *b = (const char *)tiles;
+    VKR_REQUIRE(a + (size_t)6 * n * n * 8 <= b || b + rows * 32 <= a, "vkr_tile_rgba16f_footprints: source and destination overlap");
+    hipLaunchKernelGGL(footprint_tiles_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       (const uint2 *)linear, (uint4 *)tiles, n, (unsigned)k, (unsigned)rows);
+    return launch_status("vkr_tile_rgba16f_footprints");
+}
+
+namespace vkr {
+static int64_t irr_rows_partial_floats(int env_n, int n_texels)
+{
+    int per_side, cpr;
+    irr_region_grid(env_n, &per_side, &cpr);
+    const int64_t n_groups = (n_texels + IRR_GROUP - 1) / IRR_GROUP;
+    return (int64_t)6 * per_side * per_side * 4 * n_groups * IRR_GROUP;
+}
+}  // namespace vkr
+
+extern "C" int64_t vkr_ibl_irradiance_by_region_rows_workspace_bytes(int32_t env_n, int32_t n, int32_t row_begin, int32_t row_end)
+{
+    using namespace vkr;
+    if (env_n <= 0 || env_n > 8192 || n <= 0 || n > 4096 || row_begin < 0 || row_end < row_begin || row_end > 6 * n) {
+        fail(VKR_ERR_INVALID, "vkr_ibl_irradiance_by_region_rows_workspace_bytes: bad sizes (env %d, cube %d, rows [%d,%d))", env_n, n, row_begin, row_end);
+        return -1;
+    }
+    return irr_rows_partial_floats(env_n, n * (row_end - row_begin)) * 4 + 256;
+}
+
+extern "C" int32_t vkr_ibl_irradiance_by_region_rows(const void *env_tiles, int32_t env_n, void *out, int32_t n, int32_t row_begin, int32_t row_end,
+                                                     void *workspace, int64_t workspace_bytes, void *stream)
+{
+    using namespace vkr;
+    const char *who = "vkr_ibl_irradiance_by_region_rows";
+    VKR_REQUIRE(env_tiles && out && env_n > 0, "%s: an image is null or env size is bad", who);
+    VKR_REQUIRE(env_n <= 8192 && n <= 4096, "%s: sizes beyond 8192 (environment) or 4096 (irradiance cube): %d, %d", who, env_n, n);
+    int32_t rc = check_rows(who, n, 6 * n, row_begin, row_end);
+    if (rc != VKR_OK) return rc;
+    const int n_texels = n * (row_end - row_begin);
+    const int64_t floats = irr_rows_partial_floats(env_n, n_texels), need = floats * 4 + 256;
+    VKR_REQUIRE(workspace != nullptr && workspace_bytes >= need, "%s: workspace of %lld bytes, %lld needed", who, (long long)workspace_bytes, (long long)need);
+    VKR_REQUIRE(((uintptr_t)workspace & 3u) == 0 && ((uintptr_t)env_tiles & 7u) == 0, "%s: workspace is not 4-byte aligned or the environment not 8-byte aligned", who);
+    if ((rc = ensure_tables()) != VKR_OK) return rc;
+    if (n_texels == 0) return VKR_OK;
+    int per_side, cpr;
+    irr_region_grid(env_n, &per_side, &cpr);
+    const int n_regions = 6 * per_side * per_side, n_groups = (n_texels + IRR_GROUP - 1) / IRR_GROUP;
+    const int64_t workgroups = (int64_t)((n_regions + 7) / 8) * 8 * n_groups;
+    VKR_REQUIRE(workgroups < (1ll << 31), "%s: too much work for one call, pass fewer rows", who);
+    float *partial = (float *)workspace;
+    uint32_t *uncovered = (uint32_t *)(partial + floats);
+    hipStream_t s = as_stream(stream);
+    VKR_HIP_CHECK(hipMemsetAsync(uncovered, 0, 4, s));
+    hipLaunchKernelGGL(irradiance_rows_kernel, dim3((unsigned)workgroups), dim3(256), 0, s,
+                       (const char *)env_tiles, env_n, (unsigned)footprint_tiles_per_side(env_n), n, g_irr_nphi, g_irr_ntheta, row_begin, n_texels, partial, per_side, cpr, n_regions, n_groups);
+    if ((rc = launch_status(who)) != VKR_OK) return rc;
+    hipLaunchKernelGGL(irradiance_regions_sum_kernel, dim3((n_texels + 255) / 256), dim3(256), 0, s,
+                       partial, n_regions, n_groups, (uint2 *)out, n, g_irr_nphi, g_irr_ntheta, row_begin, n_texels, uncovered);
+    return launch_status(who);
 }
 
 extern "C" int32_t vkr_ibl_prefilter(const void *env, int32_t env_n, int32_t env_layout, void *out, int32_t n, float roughness, int32_t row_begin, int32_t row_end, void *stream)

@@ -448,8 +448,11 @@ extern "C" int32_t vkr_bloom_postprocess(const VkrBloomChainArgs *a, void *strea
     // sixteen waves per CU (one round of four per SIMD) and stay between 16 rows (apron 50 %) and 32 (25 %)
     const int tiles_x = (a->width + BF_COLS - 1) / BF_COLS;
     long band = ((long)a->rows * tiles_x + 4095) / 4096;
-    static const int forced_band = getenv("VKR_BF_BAND") ? atoi(getenv("VKR_BF_BAND")) : 0;  // experiments
-    p.band = forced_band > 0 ? forced_band : (int)(band < 16 ? 16 : band > 32 ? 32 : band);
+    p.band = (int)(band < 16 ? 16 : band > 32 ? 32 : band);
+#ifdef VKR_EXPERIMENT_KNOBS  // kernel experiments only: the shipped library reads no environment
+    static const int forced_band = getenv("VKR_BF_BAND") ? atoi(getenv("VKR_BF_BAND")) : 0;
+    if (forced_band > 0) p.band = forced_band;
+#endif
     dim3 grid(tiles_x, (a->rows + p.band - 1) / p.band);
     const bool srgb = (a->flags & VKR_POST_SRGB_TARGET) != 0;
     const bool even_repeat = (a->width & 1) == 0 && a->wrap_h == VKR_WRAP_REPEAT;

@@ -715,8 +715,12 @@ extern "C" int32_t vkr_shade(const VkrShadeArgs *a, void *stream)
     // skip different lights, and with them the shadow cubes the resident waves of an XCD read from drift apart too,
     // until that XCD's L2 no longer holds them.  A cut costs a re-read of the G-buffer and the targets (48 bytes per
     // pixel) and changes no bit: between two draws the targets are binary16 values, in registers or in memory.
-    static const int forced_chunk = getenv("VKR_SHADE_CHUNK") ? atoi(getenv("VKR_SHADE_CHUNK")) : -1;  // experiments; 0: one launch
+#ifdef VKR_EXPERIMENT_KNOBS  // kernel experiments only (make HIPFLAGS+=-DVKR_EXPERIMENT_KNOBS): the shipped library reads no environment
+    static const int forced_chunk = getenv("VKR_SHADE_CHUNK") ? atoi(getenv("VKR_SHADE_CHUNK")) : -1;  // 0: one launch
     const int chunk = forced_chunk > 0 ? forced_chunk : (forced_chunk == 0 ? a->n_lights : SHADE_LIGHTS_PER_LAUNCH);
+#else
+    const int chunk = SHADE_LIGHTS_PER_LAUNCH;
+#endif
     p.light_begin = 0;
     do {
         p.light_end = a->n_lights - p.light_begin <= chunk + chunk / 2 ? a->n_lights : p.light_begin + chunk;  // no short tail launch

@@ -313,10 +313,37 @@ def tile_env_cube(linear: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def tile_env_footprints(linear: torch.Tensor) -> torch.Tensor:
+    """[6, n, n, 4] float16 cube, row-major -> the cube in footprint tiles (VKR_ENV_LAYOUT_FOOTPRINT_TILES): a flat
+    uint8 tensor of vkr_env_footprint_tiles_bytes(n) bytes."""
+    lib = _lib.load()
+    n = linear.shape[1]
+    need = lib.vkr_env_footprint_tiles_bytes(n)
+    if need < 0:
+        _lib.check(_lib.VKR_ERR_INVALID)
+    out = torch.empty(need, dtype=torch.uint8, device=linear.device)
+    _lib.check(lib.vkr_tile_rgba16f_footprints(_ptr(linear), _ptr(out), n, _stream()))
+    return out
+
+
 def irradiance(env: torch.Tensor, out: torch.Tensor, order: int = _lib.IRRADIANCE_SEQUENTIAL, rows=None,
                env_layout: int = _lib.ENV_LAYOUT_LINEAR) -> None:
+    """One of the summation orders of the irradiance pass.  The two by-region orders allocate their workspace here
+    (the rows order also its footprint tiles, from a row-major `env`) and check that every sample was accounted for,
+    which synchronises; a caller that wants neither uses irradiance_by_region() / irradiance_by_region_rows()."""
+    if order == _lib.IRRADIANCE_FASTEST:
+        order = _lib.IRRADIANCE_BY_REGION_ROWS
     if order == _lib.IRRADIANCE_BY_REGION:
-        irradiance_by_region(env, out, rows, env_layout)
+        ws = irradiance_by_region(env, out, rows, env_layout)
+        _require_all_samples(ws, "VKR_IRRADIANCE_BY_REGION")
+        return
+    if order == _lib.IRRADIANCE_BY_REGION_ROWS:
+        if env_layout == _lib.ENV_LAYOUT_FOOTPRINT_TILES:
+            raise ValueError("pass the row-major cube here, or call irradiance_by_region_rows() with the tiles and the face size")
+        if env_layout != _lib.ENV_LAYOUT_LINEAR:
+            raise ValueError("the rows order reads footprint tiles, which are made from the row-major cube")
+        ws = irradiance_by_region_rows(tile_env_footprints(env), env.shape[1], out, rows)
+        _require_all_samples(ws, "VKR_IRRADIANCE_BY_REGION_ROWS")
         return
     lib = _lib.load()
     n = out.shape[1]
@@ -339,6 +366,30 @@ def irradiance_by_region(env: torch.Tensor, out: torch.Tensor, rows=None, env_la
     _lib.check(lib.vkr_ibl_irradiance_by_region(_ptr(env), env.shape[1], env_layout, _ptr(out), n, r0, r1,
                                                 _ptr(workspace), workspace.numel(), _stream()))
     return workspace
+
+
+def irradiance_by_region_rows(env_tiles: torch.Tensor, env_n: int, out: torch.Tensor, rows=None,
+                              workspace: torch.Tensor | None = None) -> torch.Tensor:
+    """The irradiance cube in the VKR_IRRADIANCE_BY_REGION_ROWS order from the environment in footprint tiles
+    (tile_env_footprints).  Returns the workspace; irradiance_uncovered() reads its check word."""
+    lib = _lib.load()
+    n = out.shape[1]
+    r0, r1 = _rows(6 * n, rows)
+    need = lib.vkr_ibl_irradiance_by_region_rows_workspace_bytes(env_n, n, r0, r1)
+    if need < 0:
+        _lib.check(_lib.VKR_ERR_INVALID)
+    if workspace is None:
+        workspace = torch.empty(need, dtype=torch.uint8, device=out.device)
+    _lib.check(lib.vkr_ibl_irradiance_by_region_rows(_ptr(env_tiles), env_n, _ptr(out), n, r0, r1,
+                                                     _ptr(workspace), workspace.numel(), _stream()))
+    return workspace
+
+
+def _require_all_samples(workspace: torch.Tensor, what: str) -> None:
+    missing = irradiance_uncovered(workspace)
+    if missing:
+        raise RuntimeError(f"{what}: {missing} texels did not find all of their samples (written as NaN); "
+                           "the kernel's culling bounds have a flaw at these sizes -- use VKR_IRRADIANCE_SEQUENTIAL and report it")
 
 
 def irradiance_uncovered(workspace: torch.Tensor, need: int | None = None) -> int:
