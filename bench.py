@@ -41,6 +41,7 @@ C5_WIDTH, C5_ROWS, C5_LIGHTS = 16384, 2048, 256  # per-GPU share of the 16384^2 
 SEED = 0x5EED0003
 PEAK_FP32_TFLOPS = 157.3   # MI355X FP32 vector peak
 PEAK_HBM_GBS = 8000.0      # MI355X HBM3E peak
+L2_RANDOM_LINE_GBS = 34450.0  # random 128-byte lines out of an L2-resident table, all CUs (profiles/r2_gather_bench.txt)
 OPS_PER_PIXEL = 504        # canonical FP32 ops per pixel outside the light loop
 OPS_PER_PIXEL_LIGHT = 810  # canonical FP32 ops per (pixel, light) pair
 # canonical FP32 ops per IBL sample / texel (the same counting convention as the two figures above)
@@ -321,51 +322,71 @@ def time_ibl(device, reps: int = 3) -> tuple[dict, list]:
     irr = torch.empty((6, 64, 64, 4), dtype=torch.float16, device=device)
     pres = [torch.empty((6, 128 >> m, 128 >> m, 4), dtype=torch.float16, device=device) for m in range(5)]
     lut = torch.empty((512, 512, 2), dtype=torch.float16, device=device)
-    tiled_box = [None]
+    irr_seq, irr_reg = torch.empty_like(irr), torch.empty_like(irr)
+    box = {}
 
     def run():
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(10)]
+        """The precompute as a renderer runs it: the irradiance pass in the library's default order (by region of the
+        environment with row sums, from footprint tiles)."""
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
         ev[0].record()
         P.equirect_to_cube(src, _lib.SRC_RGBA16F, env)
         ev[1].record()
-        tiled = tiled_box[0] = P.tile_env_cube(env)  # the copy the two sampling passes read; counted with the equirect stage
+        box["tiled"] = P.tile_env_cube(env)  # the copy the prefilter passes read
         ev[2].record()
-        P.irradiance(tiled, irr, _lib.IRRADIANCE_SEQUENTIAL, env_layout=_lib.ENV_LAYOUT_TILED_4X4)
+        box["foot"] = P.tile_env_footprints(env)  # the copy the irradiance pass reads
         ev[3].record()
+        box["ws"] = P.irradiance_by_region_rows(box["foot"], 2048, irr, workspace=box.get("ws"))
+        ev[4].record()
         for m in range(5):
-            P.prefilter(tiled, pres[m], m / 4.0, env_layout=_lib.ENV_LAYOUT_TILED_4X4)
-            ev[4 + m].record()
+            P.prefilter(box["tiled"], pres[m], m / 4.0, env_layout=_lib.ENV_LAYOUT_TILED_4X4)
+            ev[5 + m].record()
         P.brdf_lut(lut)
-        ev[9].record()
+        ev[10].record()
         torch.cuda.synchronize()
-        return [ev[i].elapsed_time(ev[i + 1]) for i in range(9)]
+        return [ev[i].elapsed_time(ev[i + 1]) for i in range(10)]
 
     run()
     t = np.mean([run() for _ in range(reps)], axis=0)
-    eq, tile, irr_ms, pre_ms, lut_ms = t[0], t[1], t[2], t[3:8], t[8]
+    eq, tile, foot, irr_ms, pre_ms, lut_ms = t[0], t[1], t[2], t[3], t[4:9], t[9]
+    uncovered = P.irradiance_uncovered(box["ws"])
 
-    # the opt-in summation order that works through the environment region by region (same samples, other rounding)
-    irr_r = torch.empty_like(irr)
-    ws = P.irradiance_by_region(tiled_box[0], irr_r, env_layout=_lib.ENV_LAYOUT_TILED_4X4)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        P.irradiance_by_region(tiled_box[0], irr_r, env_layout=_lib.ENV_LAYOUT_TILED_4X4, workspace=ws)
-    e1.record()
-    torch.cuda.synchronize()
-    region_ms = e0.elapsed_time(e1) / reps
-    a, b = irr.float().cpu().numpy(), irr_r.float().cpu().numpy()
+    def timed(fn):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    # beside it: the shader's own summation order (one running sum per texel), and the first by-region order
+    seq_ms = timed(lambda: P.irradiance(box["tiled"], irr_seq, _lib.IRRADIANCE_SEQUENTIAL, env_layout=_lib.ENV_LAYOUT_TILED_4X4))
+    ws2 = P.irradiance_by_region(box["tiled"], irr_reg, env_layout=_lib.ENV_LAYOUT_TILED_4X4)
+    region_ms = timed(lambda: P.irradiance_by_region(box["tiled"], irr_reg, env_layout=_lib.ENV_LAYOUT_TILED_4X4, workspace=ws2))
+    a = irr_seq.float().cpu().numpy()
     ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(a), 2.0 ** -14))) - 10)
-    by_region = {"irradiance_ms": round(float(region_ms), 3), "total_ms": round(float(t.sum() - irr_ms + region_ms), 3),
-                 "workspace_bytes": int(ws.numel()), "texels_with_samples_unaccounted_for": P.irradiance_uncovered(ws),
-                 "texels_that_differ_from_the_shader_order": int((P.f16_bits(irr) != P.f16_bits(irr_r)).any(-1).sum()),
-                 "of_texels": int(irr.shape[0] * irr.shape[1] * irr.shape[2]), "max_difference_binary16_ulps": round(float((np.abs(a - b) / ulp).max()), 2),
-                 "note": "VKR_IRRADIANCE_BY_REGION: bit-exact against its own restatement in oracle/, not the order the reference's shader adds in; not part of total_ms"}
-    stages = {"equirect_ms": round(float(eq + tile), 3), "irradiance_ms": round(float(irr_ms), 3), "prefilter_ms": round(float(pre_ms.sum()), 3),
+
+    def against_shader_order(img):
+        b = img.float().cpu().numpy()
+        return {"texels_that_differ": int((P.f16_bits(irr_seq) != P.f16_bits(img)).any(-1).sum()), "of_texels": int(a.shape[0] * a.shape[1] * a.shape[2]),
+                "max_difference_binary16_ulps": round(float((np.abs(a - b) / ulp).max()), 2)}
+
+    orders = {"by_region_rows (default, timed in total_ms)": {"irradiance_ms": round(float(irr_ms), 3), "footprint_tiles_ms": round(float(foot), 3),
+                                                              "workspace_bytes": int(box["ws"].numel()), "footprint_tile_bytes": int(box["foot"].numel()),
+                                                              "texels_with_samples_unaccounted_for": uncovered, "against_the_shader_order": against_shader_order(irr)},
+              "sequential (the shader's running sum)": {"irradiance_ms": round(float(seq_ms), 3), "total_ms": round(float(t.sum() - irr_ms - foot + seq_ms), 3)},
+              "by_region": {"irradiance_ms": round(float(region_ms), 3), "total_ms": round(float(t.sum() - irr_ms - foot + region_ms), 3),
+                            "texels_with_samples_unaccounted_for": P.irradiance_uncovered(ws2), "against_the_shader_order": against_shader_order(irr_reg)},
+              "note": "every order is bit-exact against its own restatement in oracle/ (orc_irradiance, order 0 / 2 / 3); the by-region orders add the same "
+                      "15 876 samples per texel in another order and stay within one binary16 ulp of the shader's"}
+    stages = {"equirect_ms": round(float(eq + tile + foot), 3), "irradiance_ms": round(float(irr_ms), 3), "prefilter_ms": round(float(pre_ms.sum()), 3),
               "brdf_lut_ms": round(float(lut_ms), 3), "total_ms": round(float(t.sum()), 3),
-              "config": "equirect 4096x2048 RGBA16F -> env 2048^2 (+ 4x4-tiled copy), irradiance 64^2 in the shader's summation order, "
-                        "prefilter 128^2 x5 mips, LUT 512^2",
-              "irradiance_by_region": by_region}
+              "total_ms_with_the_shader_summation_order": round(float(t.sum() - irr_ms - foot + seq_ms), 3),
+              "config": "equirect 4096x2048 RGBA16F -> env 2048^2 (+ 4x4-tiled copy for the prefilter, footprint-tile copy for the irradiance pass), "
+                        "irradiance 64^2 in the library's default order (VKR_IRRADIANCE_BY_REGION_ROWS), prefilter 128^2 x5 mips, LUT 512^2",
+              "irradiance_orders": orders}
 
     def valu(kernel, ops, ms, algorithmic, **more):
         tf = ops / (ms * 1e-3) / 1e12
@@ -381,32 +402,27 @@ def time_ibl(device, reps: int = 3) -> tuple[dict, list]:
     env_bytes, src_bytes = env.numel() * 2, src.numel() * 2
     # every irradiance sample gathers the 2x2 footprint of a bilinear lookup (4 texels x 8 B) from the 201 MB cube
     gather_bytes = irr_texels * IRRADIANCE_SAMPLES * 32
+    samples = IRRADIANCE_SAMPLES * irr_texels
     roof = [
         hbm("equirect_kernel", env_bytes + src_bytes, eq, f"{env_bytes} B written (8 B/texel) + {src_bytes} B source read once"),
         hbm("tile_rgba16f_kernel", 2 * env_bytes, tile, f"{env_bytes} B read + {env_bytes} B written"),
-        valu("irradiance_texel_kernel", OPS_IRRADIANCE_SAMPLE * IRRADIANCE_SAMPLES * irr_texels, irr_ms,
+        hbm("footprint_tiles_kernel", env_bytes + int(box["foot"].numel()), foot, f"{env_bytes} B read + {int(box['foot'].numel())} B written (16/9 of the cube)"),
+        valu("irradiance_rows_kernel (+ irradiance_regions_sum_kernel)", OPS_IRRADIANCE_SAMPLE * samples, irr_ms,
+             f"{OPS_IRRADIANCE_SAMPLE} FP32 ops x {IRRADIANCE_SAMPLES} samples x {irr_texels} texels (the default order; the kernel also decides about 1.05 "
+             "cells per sample, which the figure does not count)",
+             # what bounds it: every sample pulls the one 128-byte line that holds its 2x2 footprint from L2 (hit rate 97 %); the ceiling is the
+             # rate at which random lines come out of an L2-resident table
+             l2_lines={"bound": "L2 -> L1 cache lines", "bytes": samples * 128, "achieved": round(samples * 128 / (irr_ms * 1e-3) / 1e9, 1),
+                       "peak": L2_RANDOM_LINE_GBS, "unit": "GB/s", "frac": round(samples * 128 / (irr_ms * 1e-3) / 1e9 / L2_RANDOM_LINE_GBS, 4),
+                       "source": "one 128-byte line per sample (footprint tiles); peak = random 128-byte lines from a 2 MiB table, "
+                                 "profiles/r2_gather_bench.txt (scratch/ubench/gather_bench), = 16 channels x 128 B x 8 XCDs x 2.1 GHz"}),
+        valu("irradiance_texel_kernel (the shader's order)", OPS_IRRADIANCE_SAMPLE * samples, seq_ms,
              f"{OPS_IRRADIANCE_SAMPLE} FP32 ops x {IRRADIANCE_SAMPLES} samples x {irr_texels} texels",
-             gather={"bytes": gather_bytes, "GB/s": round(gather_bytes / (irr_ms * 1e-3) / 1e9, 1),
-                     "note": "32 B of texels per bilinear sample, served by L1/L2/Infinity Cache; the memory-side line traffic is in profiles/"}),
+             gather={"bytes": gather_bytes, "GB/s": round(gather_bytes / (seq_ms * 1e-3) / 1e9, 1),
+                     "note": "32 B of texels per bilinear sample; bound by L2-miss line traffic (70.6 GB per launch, profiles/r2_counters.json)"}),
+        valu("irradiance_region_kernel (+ irradiance_regions_sum_kernel)", OPS_IRRADIANCE_SAMPLE * samples, region_ms,
+             f"{OPS_IRRADIANCE_SAMPLE} FP32 ops x {IRRADIANCE_SAMPLES} samples x {irr_texels} texels (the first by-region order)"),
     ]
-    # The irradiance kernel is bound by the rate at which the path behind a missing L2 delivers cache lines (every
-    # bilinear tap lands on a different line of a 201 MB cube), not by its arithmetic: set its L2-miss line traffic
-    # (committed counter passes of the same kernel and sizes) beside the rate a pure random-line read reaches.
-    try:
-        with open(os.path.join(ROOT, COUNTER_FILE)) as fh:
-            crec = json.load(fh)
-        lines = crec["ibl"]["kernels"]["irradiance_texel_kernel"]["l2_miss_line_bytes"]
-        ceiling = crec["random_line_read_GBps"]["by_table_size"]["256 MiB"]
-        rate = lines / (irr_ms * 1e-3) / 1e9
-        roof[-1]["line_traffic"] = {"bound": "l2-miss line reads", "bytes": lines, "achieved": round(rate, 1), "peak": ceiling, "unit": "GB/s",
-                                    "frac": round(rate / ceiling, 4), "algorithmic_bytes": gather_bytes,
-                                    "source": f"{COUNTER_FILE}: TCC_MISS_sum x 128 B of one launch (scratch/pmc_ibl2.sh); peak = random 128-byte lines from a 256 MiB table "
-                                              "(scratch/ubench/gather_bench, profiles/r2_gather_bench.txt); neither is read in this run"}
-    except (OSError, KeyError):
-        pass
-    roof.append(valu("irradiance_region_kernel (+ irradiance_regions_sum_kernel)", OPS_IRRADIANCE_SAMPLE * IRRADIANCE_SAMPLES * irr_texels, region_ms,
-                     f"{OPS_IRRADIANCE_SAMPLE} FP32 ops x {IRRADIANCE_SAMPLES} samples x {irr_texels} texels (the same sum in the by-region order; the kernel "
-                     "also looks at about 1.6 candidate cells per sample that lands elsewhere, which the figure does not count)"))
     for m in range(5):
         n = 128 >> m
         roof.append(valu(f"prefilter_texel_kernel mip {m} (roughness {m / 4:g})", OPS_PREFILTER_SAMPLE * GGX_SAMPLES * 6 * n * n, pre_ms[m],
@@ -442,9 +458,9 @@ def time_ibl_sharded(rank: int, world: int, device, reps: int = 3) -> dict:
         del res
         return round(float(t.item()), 3)
 
-    return {"ms": timed(_lib.IRRADIANCE_SEQUENTIAL), "ms_with_irradiance_by_region": timed(_lib.IRRADIANCE_BY_REGION), "world": world,
+    return {"ms": timed(_lib.IRRADIANCE_FASTEST), "ms_with_the_shader_summation_order": timed(_lib.IRRADIANCE_SEQUENTIAL), "world": world,
             "config": "equirect 4096x2048 -> env 2048^2 on every rank; rows of irradiance 64^2, prefilter 128^2 x5 mips and LUT 512^2 split "
-                      "over the ranks and all-gathered; ms: the irradiance pass in the shader's summation order"}
+                      "over the ranks and all-gathered; ms: the irradiance pass in the library's default order (by region with row sums)"}
 
 
 def time_coverage(f, dev_frame, renderer, device) -> dict:

@@ -212,8 +212,9 @@ public sealed unsafe class HipRenderer : IDisposable
     public void CreateSkyboxCubemap(void* equirect, int w, int h, int format) => Check(Native.vkr_create_skybox_cubemap(ctx, equirect, w, h, format));
     /// <summary>Summation order of the irradiance pass: the shader's own running sum, or (about twice as fast, other
     /// rounding in the last binary16 digit of under 1 % of the texels) the samples grouped by region of the environment.</summary>
-    public const int IrradianceSequential = 0, IrradianceByRegion = 2;
-    public void CreateIrradianceCubemap(int order = IrradianceSequential) => Check(Native.vkr_create_irradiance_cubemap(ctx, order));
+    public const int IrradianceSequential = 0, IrradianceByRegion = 2, IrradianceByRegionRows = 3, IrradianceFastest = -1;
+    // the default order is the library's fastest; it differs from the shader's own running sum (IrradianceSequential) in rounding only
+    public void CreateIrradianceCubemap(int order = IrradianceFastest) => Check(Native.vkr_create_irradiance_cubemap(ctx, order));
     public void CreatePrefilteredCubemap() => Check(Native.vkr_create_prefiltered_cubemap(ctx));
     public void CreateBRDFLUTTexture() => Check(Native.vkr_create_brdf_lut(ctx));
 

@@ -442,7 +442,8 @@ VKR_EXPORT int32_t vkr_upload_point_shadow(vkr_ctx *ctx, int32_t light, const fl
 /* IBL precompute (synchronous, like the reference's QueueWaitIdle after each). */
 VKR_EXPORT int32_t vkr_create_skybox_cubemap(vkr_ctx *ctx, const void *equirect, int32_t w, int32_t h, int32_t src_format); /* :653 */
 VKR_EXPORT int32_t vkr_upload_env_cube(vkr_ctx *ctx, const void *rgba16f_cube);  /* an environment cube given directly */
-VKR_EXPORT int32_t vkr_create_irradiance_cubemap(vkr_ctx *ctx, int32_t order);   /* :734 */
+VKR_EXPORT int32_t vkr_create_irradiance_cubemap(vkr_ctx *ctx, int32_t order);   /* :734; order: VKR_IRRADIANCE_* (the by-region
+                                                                                  * orders allocate their workspace for the call) */
 VKR_EXPORT int32_t vkr_create_prefiltered_cubemap(vkr_ctx *ctx);                 /* :815 */
 VKR_EXPORT int32_t vkr_create_brdf_lut(vkr_ctx *ctx);                            /* :966 */
 

@@ -176,7 +176,8 @@ public:
     // IBL precompute (VulkanRenderer.cs:271-275)
     void CreateSkyboxCubemap(const void *equirect, int32_t w, int32_t h, int32_t format) { check(vkr_create_skybox_cubemap(ctx_, equirect, w, h, format)); }
     void UploadEnvironmentCubemap(const void *cube) { check(vkr_upload_env_cube(ctx_, cube)); }
-    void CreateIrradianceCubemap(int32_t order = VKR_IRRADIANCE_SEQUENTIAL) { check(vkr_create_irradiance_cubemap(ctx_, order)); }
+    // the default order is the library's fastest; it differs from the shader's own running sum (VKR_IRRADIANCE_SEQUENTIAL) in rounding only
+    void CreateIrradianceCubemap(int32_t order = VKR_IRRADIANCE_FASTEST) { check(vkr_create_irradiance_cubemap(ctx_, order)); }
     void CreatePrefilteredCubemap() { check(vkr_create_prefiltered_cubemap(ctx_)); }
     void CreateBRDFLUTTexture() { check(vkr_create_brdf_lut(ctx_)); }
 

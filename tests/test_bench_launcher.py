@@ -62,6 +62,9 @@ def test_self_launched_ranks_render_one_frame_in_strips(gpu):
     assert "48 rows" in line["config"]["workload"]
     # the IBL precompute with its rows split over the two ranks (2048^2 configuration), and rank 0's own timing of it
     assert line["ibl_precompute_sharded"]["world"] == 2 and line["ibl_precompute_sharded"]["ms"] > 0
-    assert 0 < line["ibl_precompute_sharded"]["ms_with_irradiance_by_region"] < line["ibl_precompute_sharded"]["ms"]
-    assert line["ibl_precompute"]["irradiance_by_region"]["texels_with_samples_unaccounted_for"] == 0
+    assert 0 < line["ibl_precompute_sharded"]["ms"] < line["ibl_precompute_sharded"]["ms_with_the_shader_summation_order"]
+    orders = line["ibl_precompute"]["irradiance_orders"]
+    assert orders["by_region_rows (default, timed in total_ms)"]["texels_with_samples_unaccounted_for"] == 0
+    assert orders["by_region"]["texels_with_samples_unaccounted_for"] == 0
+    assert orders["by_region_rows (default, timed in total_ms)"]["against_the_shader_order"]["max_difference_binary16_ulps"] <= 1.0
     assert line["ibl_precompute"]["total_ms"] > 0

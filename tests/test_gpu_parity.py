@@ -494,9 +494,11 @@ def test_renderer_end_frame_matches_oracle_chain(gpu, oracle):
         # IBL images computed by the library from an environment cube, then the oracle shades with the same images
         env = synth.make_env_cube(np.random.default_rng(2), 16)
         r.UploadEnvironmentCubemap(env)
-        for order in (_lib.IRRADIANCE_PHI_SLICES, _lib.IRRADIANCE_BY_REGION, _lib.IRRADIANCE_SEQUENTIAL):
+        for order in (_lib.IRRADIANCE_PHI_SLICES, _lib.IRRADIANCE_BY_REGION, _lib.IRRADIANCE_BY_REGION_ROWS, _lib.IRRADIANCE_SEQUENTIAL):
             r.CreateIrradianceCubemap(order)
             assert_bits_equal(r.Read(_lib.TARGET_IRRADIANCE), oracle.irradiance(env, 8, order), f"irradiance cube, order {order}")
+        r.CreateIrradianceCubemap()  # the default: the library's fastest order
+        assert_bits_equal(r.Read(_lib.TARGET_IRRADIANCE), oracle.irradiance(env, 8, _lib.IRRADIANCE_BY_REGION_ROWS), "irradiance cube, default order")
         r.CreatePrefilteredCubemap()
         r.CreateBRDFLUTTexture()
         f.irradiance = r.Read(_lib.TARGET_IRRADIANCE)
@@ -666,12 +668,16 @@ def test_ibl_precompute_matches_oracle_at_cube_edges_and_corners(gpu, oracle):
     """The whole precompute through vulkanrenderer_amd.ibl on sizes where most irradiance and
     prefilter samples cross face edges and some hit cube corners (64^2 environment)."""
     torch, P = _torch(), _passes()
+    import dataclasses
     from vulkanrenderer_amd.ibl import IblConfig, IblPrecompute
     cfg = IblConfig(env_res=64, irradiance_res=8, prefilter_res=16, prefilter_mips=5, lut_res=48)
     src = synth.make_equirect(np.random.default_rng(21), 256, 128, hdr=True)
     res = IblPrecompute(cfg, device=gpu).run(P.to_device_f16(src, gpu), _lib.SRC_RGBA16F)
     env = P.f16_bits(res["env"])  # the GPU's environment cube feeds both sides from here on
-    assert_bits_equal(P.f16_bits(res["irradiance"]), oracle.irradiance(env, 8, 0), "irradiance")
+    # IblConfig's default order is the library's fastest: by region of the environment with row sums
+    assert_bits_equal(P.f16_bits(res["irradiance"]), oracle.irradiance(env, 8, _lib.IRRADIANCE_BY_REGION_ROWS), "irradiance")
+    seq = IblPrecompute(dataclasses.replace(cfg, irradiance_order=_lib.IRRADIANCE_SEQUENTIAL), device=gpu).run(P.to_device_f16(src, gpu), _lib.SRC_RGBA16F)
+    assert_bits_equal(P.f16_bits(seq["irradiance"]), oracle.irradiance(env, 8, 0), "irradiance in the shader's order")
     for m, cube in enumerate(res["prefilter"]):
         assert_bits_equal(P.f16_bits(cube), oracle.prefilter(env, 16 >> m, m / 4.0), f"prefilter mip {m}")
     assert_bits_equal(P.f16_bits(res["brdf_lut"]), oracle.brdf_lut(48), "BRDF LUT")
@@ -709,7 +715,7 @@ def test_cpp_host_program_matches_oracle(gpu, oracle, tmp_path, mode):
     f.irradiance = parts[3].view(np.uint16).reshape(6, ires, ires, 4)
     f.prefilter = parts[4].view(np.uint16).reshape(6, pres, pres, 4)
     f.brdf_lut = parts[5].view(np.uint16).reshape(lres, lres, 2)
-    assert_bits_equal(f.irradiance, oracle.irradiance(env, ires, 0), "irradiance")
+    assert_bits_equal(f.irradiance, oracle.irradiance(env, ires, _lib.IRRADIANCE_BY_REGION_ROWS), "irradiance")  # the wrapper's default order
     assert_bits_equal(f.prefilter, oracle.prefilter(env, pres, 0.0), "prefilter")
     assert_bits_equal(f.brdf_lut, oracle.brdf_lut(lres), "BRDF LUT")
     want = oracle.frame_chain(f, oracle.skybox(env, f.scene, w, h))

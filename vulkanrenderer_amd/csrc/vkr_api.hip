@@ -694,16 +694,26 @@ extern "C" int32_t vkr_create_irradiance_cubemap(vkr_ctx *c, int32_t order)
     const void *env = c->env_tiled ? c->env_tiled : c->env;
     const int32_t layout = c->env_tiled ? VKR_ENV_LAYOUT_TILED_4X4 : VKR_ENV_LAYOUT_LINEAR;
     const int32_t n = c->cfg.irradiance_res;
-    if (order == VKR_IRRADIANCE_BY_REGION) {
-        // a one-off step: its workspace lives for this call only
-        const int64_t bytes = vkr_ibl_irradiance_by_region_workspace_bytes(c->cfg.env_res, n, 0, 6 * n);
-        if (bytes < 0) return VKR_ERR_INVALID;
-        void *ws = nullptr;
-        VKR_HIP_CHECK(hipMalloc(&ws, (size_t)bytes));
-        int32_t rc = vkr_ibl_irradiance_by_region(env, c->cfg.env_res, layout, c->irradiance, n, 0, 6 * n, ws, bytes, c->stream);
+    if (order == VKR_IRRADIANCE_FASTEST) order = VKR_IRRADIANCE_BY_REGION_ROWS;
+    if (order == VKR_IRRADIANCE_BY_REGION || order == VKR_IRRADIANCE_BY_REGION_ROWS) {
+        // a one-off step: the workspace (and, for the rows order, the environment in footprint tiles) lives for this call only
+        const bool rows = order == VKR_IRRADIANCE_BY_REGION_ROWS;
+        const int64_t bytes = rows ? vkr_ibl_irradiance_by_region_rows_workspace_bytes(c->cfg.env_res, n, 0, 6 * n)
+                                   : vkr_ibl_irradiance_by_region_workspace_bytes(c->cfg.env_res, n, 0, 6 * n);
+        const int64_t tile_bytes = rows ? vkr_env_footprint_tiles_bytes(c->cfg.env_res) : 0;
+        if (bytes < 0 || tile_bytes < 0) return VKR_ERR_INVALID;
+        char *ws = nullptr;  // [workspace][tiles], the tiles 256-byte aligned
+        const int64_t tiles_at = (bytes + 255) & ~(int64_t)255;
+        VKR_HIP_CHECK(hipMalloc((void **)&ws, (size_t)(tiles_at + tile_bytes)));
+        int32_t rc = VKR_OK;
+        if (rows) {
+            rc = vkr_tile_rgba16f_footprints(c->env, ws + tiles_at, c->cfg.env_res, c->stream);
+            if (rc == VKR_OK) rc = vkr_ibl_irradiance_by_region_rows(ws + tiles_at, c->cfg.env_res, c->irradiance, n, 0, 6 * n, ws, bytes, c->stream);
+        } else
+            rc = vkr_ibl_irradiance_by_region(env, c->cfg.env_res, layout, c->irradiance, n, 0, 6 * n, ws, bytes, c->stream);
         uint32_t uncovered = 0;
         hipError_t e = hipStreamSynchronize(c->stream);
-        if (rc == VKR_OK && e == hipSuccess) e = hipMemcpy(&uncovered, (const char *)ws + bytes - 256, 4, hipMemcpyDeviceToHost);
+        if (rc == VKR_OK && e == hipSuccess) e = hipMemcpy(&uncovered, ws + bytes - 256, 4, hipMemcpyDeviceToHost);
         (void)hipFree(ws);
         if (rc != VKR_OK) return rc;
         if (e != hipSuccess) return fail(VKR_ERR_HIP, "vkr_create_irradiance_cubemap: %s", hipGetErrorString(e));

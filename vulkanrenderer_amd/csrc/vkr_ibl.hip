@@ -608,30 +608,124 @@ __global__ __launch_bounds__(256) void footprint_tiles_kernel(const uint2 *src, 
 
 typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 
-// LINEAR lookup at the unrounded texel coordinates (x, y) = (s n - 1/2, t n - 1/2) of a face stored in footprint tiles
-// (`face` points at the face's first tile): the arithmetic of texcube_fetch_footprint, the four texels from one tile.
-VKR_DEV f3 fetch_footprint_tile(const char *face, int n, unsigned tiles_per_side, float x, float y)
+// fma(w, t, acc) with t the low / high binary16 half of `packed`, converted on the way in (exact): one instruction
+// where a conversion and an fma would be two
+VKR_DEV float fma_mix_lo(float w, uint32_t packed, float acc)
 {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(w), "v"(packed), "v"(acc));
+    return r;
+}
+VKR_DEV float fma_mix_hi(float w, uint32_t packed, float acc)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(w), "v"(packed), "v"(acc));
+    return r;
+}
+
+// A LINEAR lookup in a face stored in footprint tiles, in two steps: where the footprint lies, and the filtering of its
+// texels.  (Issuing the loads of a lane's next sample before the current one is filtered was measured and is slower:
+// the kernel is bound by the rate at which the L2 hands out cache lines, not by the latency of one.)
+// irr_footprint_at: from the unrounded texel coordinates (x, y) = (s n - 1/2, t n - 1/2), the arithmetic of
+// texcube_fetch_footprint: the weights' fractions and the byte offset of the footprint's first texel in the face.
+// tile_row_step = 128 * tiles_per_side - 96: with (I0, J0) the footprint's base texel shifted by one and (k, m) =
+// (I0 / 3, J0 / 3) its tile, that texel lies at ((m * tiles_per_side + k) << 7) + (((J0 - 3m) << 2) + (I0 - 3k) << 3)
+// = m * tile_row_step + 104 k + 32 J0 + 8 I0 bytes.  `missing`: at a corner of the cube the number (0 .. 3) of the
+// footprint's texel beyond both edges, otherwise -1; only looked for where the region touches a corner of its face
+// (`corners`, uniform for the workgroup).
+struct irr_footprint { unsigned at; float al, be; int missing; };
+VKR_DEV irr_footprint irr_footprint_at(int n, unsigned tile_row_step, bool corners, float x, float y)
+{
+    irr_footprint fp;
     const float fx = __builtin_floorf(x), fy = __builtin_floorf(y);
-    const float al = x - fx, be = y - fy;
+    fp.al = x - fx; fp.be = y - fy;
     const unsigned I0 = (unsigned)((int)fx + 1), J0 = (unsigned)((int)fy + 1);  // in [0, n]
-    const unsigned k = div3(I0), m = div3(J0);
-    const unsigned at = ((m * tiles_per_side + k) << 7) + ((((J0 - 3u * m) << 2) + (I0 - 3u * k)) << 3);
-    const u32x4_a8 r0 = *(const u32x4_a8 *)(face + at), r1 = *(const u32x4_a8 *)(face + at + 32u);
+    const unsigned k = __umul24(I0, 43691u) >> 17, m = __umul24(J0, 43691u) >> 17;  // / 3, exact below 98 304
+    fp.at = __umul24(m, tile_row_step) + (__umul24(k, 104u) + ((J0 << 5) + (I0 << 3)));
+    fp.missing = -1;
+    if (corners) {
+        const bool x_edge = I0 == 0u || I0 == (unsigned)n, y_edge = J0 == 0u || J0 == (unsigned)n;
+        if (x_edge && y_edge) fp.missing = (int)((I0 == 0u ? 0u : 1u) | (J0 == 0u ? 0u : 2u));
+    }
+    return fp;
+}
+// the filtered colour from the footprint's two rows of texels (r0: texels 0 and 1, r1: texels 2 and 3)
+VKR_DEV f3 irr_footprint_filter(const irr_footprint &fp, bool corners, u32x4_a8 r0, u32x4_a8 r1)
+{
+    const float al = fp.al, be = fp.be;
+    const float w0 = (1.0f - al) * (1.0f - be), w1 = al * (1.0f - be), w2 = (1.0f - al) * be, w3 = al * be;
+    if (!corners) {
+        // the binary16 texels go into the fmas as they are (v_fma_mix_f32 converts on the way in: the same values, twelve
+        // conversions fewer); w0 * t0 as fma(w0, t0, -0), which has the product's bits whatever its sign
+        const float z = -0.0f;
+        return mk3(fma_mix_lo(w3, r1.z, fma_mix_lo(w2, r1.x, fma_mix_lo(w1, r0.z, fma_mix_lo(w0, r0.x, z)))),
+                   fma_mix_hi(w3, r1.z, fma_mix_hi(w2, r1.x, fma_mix_hi(w1, r0.z, fma_mix_hi(w0, r0.x, z)))),
+                   fma_mix_lo(w3, r1.w, fma_mix_lo(w2, r1.y, fma_mix_lo(w1, r0.w, fma_mix_lo(w0, r0.y, z)))));
+    }
     rgba tx[4] = {unpack4(make_uint2(r0.x, r0.y)), unpack4(make_uint2(r0.z, r0.w)), unpack4(make_uint2(r1.x, r1.y)), unpack4(make_uint2(r1.z, r1.w))};
-    const bool x_edge = I0 == 0u || I0 == (unsigned)n, y_edge = J0 == 0u || J0 == (unsigned)n;
-    if (__builtin_expect(x_edge && y_edge, 0)) {  // cube corner: the texel beyond both edges is the mean of the other three
-        const unsigned missing = (I0 == 0u ? 0u : 1u) | (J0 == 0u ? 0u : 2u);
+    if (__builtin_expect(fp.missing >= 0, 0)) {  // the texel beyond both edges is the mean of the other three
         float sr = 0.0f, sg = 0.0f, sb = 0.0f;
 #pragma unroll
-        for (int q = 0; q < 4; q++) if ((unsigned)q != missing) { sr += tx[q].r; sg += tx[q].g; sb += tx[q].b; }
+        for (int q = 0; q < 4; q++) if (q != fp.missing) { sr += tx[q].r; sg += tx[q].g; sb += tx[q].b; }
 #pragma unroll
-        for (int q = 0; q < 4; q++) if ((unsigned)q == missing) { tx[q].r = sr * (1.0f / 3.0f); tx[q].g = sg * (1.0f / 3.0f); tx[q].b = sb * (1.0f / 3.0f); }
+        for (int q = 0; q < 4; q++) if (q == fp.missing) { tx[q].r = sr * (1.0f / 3.0f); tx[q].g = sg * (1.0f / 3.0f); tx[q].b = sb * (1.0f / 3.0f); }
     }
-    const float w0 = (1.0f - al) * (1.0f - be), w1 = al * (1.0f - be), w2 = (1.0f - al) * be, w3 = al * be;
     return mk3(fma_(w3, tx[3].r, fma_(w2, tx[2].r, fma_(w1, tx[1].r, w0 * tx[0].r))),
                fma_(w3, tx[3].g, fma_(w2, tx[2].g, fma_(w1, tx[1].g, w0 * tx[0].g))),
                fma_(w3, tx[3].b, fma_(w2, tx[2].b, fma_(w1, tx[1].b, w0 * tx[0].b))));
+}
+
+// One phi row of a (texel, region) pair: the cells bl .. bh of the row are decided exactly and what lands in the region
+// is added to the row's sum (theta ascending).  The face's class is a template argument so that the rules for ties
+// between axes are one comparison each: SC_LATER / TC_LATER -- cube_face looks at the axis of sc / tc after the major
+// axis (then the major axis wins a tie, otherwise it loses it); POSITIVE -- the face on the positive half axis.
+struct irr_row_walk {
+    const char *face; int env_n; unsigned tile_row_step; bool corners; float nf;
+    float x_lo, x_hi, y_lo, y_hi;
+};
+struct irr_cell { bool take; irr_footprint fp; float st, ct; };
+template <bool SC_LATER, bool TC_LATER, bool POSITIVE>
+VKR_DEV irr_cell irr_locate_cell(const irr_row_walk &w, float2 tsc, f3 N, f3 right, f3 up, float2 pcs, bool every)
+{
+    irr_cell c;
+    const float st = tsc.x, ct = tsc.y;
+    const float tx = st * pcs.x, ty = st * pcs.y, tz = ct;
+    // the direction in the face's coordinates; it lies on the face when cube_face would pick it (ties: z over y over x)
+    const float sc = fma_(tz, N.x, fma_(ty, up.x, tx * right.x));
+    const float tc = fma_(tz, N.y, fma_(ty, up.y, tx * right.y));
+    const float mj = fma_(tz, N.z, fma_(ty, up.z, tx * right.z));
+    const float asc = __builtin_fabsf(sc), atc = __builtin_fabsf(tc), ma = __builtin_fabsf(mj);
+    const bool over_s = SC_LATER ? ma >= asc : !(asc >= ma);
+    const bool over_t = TC_LATER ? ma >= atc : !(atc >= ma);
+    const bool side = POSITIVE ? mj >= 0.0f : !(mj <= 0.0f);
+    // a direction on this face has |major| >= 1/2 (the direction's length is within rounding of 1), inside the range
+    // of the short reciprocal; for any other the quotient is not used
+    const float ima = fast_rcp_rn(ma);
+    const float s_ = fma_(sc * ima, 0.5f, 0.5f), t_ = fma_(tc * ima, 0.5f, 0.5f);
+    const float x = s_ * w.nf - 0.5f, y = t_ * w.nf - 0.5f;
+    const bool inside = x >= w.x_lo && x < w.x_hi && y >= w.y_lo && y < w.y_hi;
+    c.take = (over_s && over_t && side && inside) || every;
+    c.fp = irr_footprint_at(w.env_n, w.tile_row_step, w.corners, x, y);
+    c.st = st; c.ct = ct;
+    return c;
+}
+template <bool SC_LATER, bool TC_LATER, bool POSITIVE>
+VKR_DEV float4 irr_walk_row(const irr_row_walk &w, const float2 *theta_sc, f3 N, f3 right, f3 up, float2 pcs, int bl, int bh, bool every)
+{
+    float sr = 0.0f, sg = 0.0f, sb = 0.0f;
+    int found = 0;
+    for (int b = bl; b <= bh; b++) {
+        const irr_cell c = irr_locate_cell<SC_LATER, TC_LATER, POSITIVE>(w, theta_sc[b], N, right, up, pcs, every);
+        if (c.take) {
+            const u32x4_a8 r0 = *(const u32x4_a8 *)(w.face + c.fp.at), r1 = *(const u32x4_a8 *)(w.face + c.fp.at + 32u);
+            const f3 col = irr_footprint_filter(c.fp, w.corners, r0, r1);
+            sr = fma_(col.x * c.ct, c.st, sr);
+            sg = fma_(col.y * c.ct, c.st, sg);
+            sb = fma_(col.z * c.ct, c.st, sb);
+            found++;
+        }
+    }
+    return make_float4(sr, sg, sb, (float)found);
 }
 
 // partial: [region][4][texels_padded] as for irradiance_region_kernel; irradiance_regions_sum_kernel adds the regions
@@ -662,10 +756,13 @@ __global__ __launch_bounds__(256) void irradiance_rows_kernel(const char *env, i
     const int rf = region % 6, cell = region / 6;
     const int rx = cell % regions_per_side, ry = cell / regions_per_side;
     const irr_region_rect geo = irr_region_geometry(env_n, regions_per_side, cells_per_region, rx, ry);
-    const bool sc_later = (rf >> 1) >= 1;  // sc is x on the y and z faces, z on the x faces
-    const bool tc_later = (rf >> 1) == 2;  // tc is y on the z faces, z or y (looked at earlier) on the others
-    const bool positive = (rf & 1) == 0;
-    const char *face = env + (size_t)rf * tiles_per_side * tiles_per_side * 128u;
+    // sc is x on the y and z faces (looked at after the major axis), z on the x faces; tc is y on the z faces, z or y
+    // (looked at earlier) on the others: the template arguments of irr_walk_row below
+    irr_row_walk walk;
+    walk.face = env + (size_t)rf * tiles_per_side * tiles_per_side * 128u;
+    walk.env_n = env_n; walk.tile_row_step = 128u * tiles_per_side - 96u; walk.nf = (float)env_n;
+    walk.corners = (rx == 0 || rx == regions_per_side - 1) && (ry == 0 || ry == regions_per_side - 1);
+    walk.x_lo = geo.x_lo; walk.x_hi = geo.x_hi; walk.y_lo = geo.y_lo; walk.y_hi = geo.y_hi;
     for (int t = tid; t < nphi; t += 256) phi_cs[t] = g_irr_phi_cs[t];
     if (tid < ntheta) theta_sc[tid] = g_irr_theta_sc[tid];
     if (tid < IRR_LEN_BINS) len_count[tid] = 0u;
@@ -698,7 +795,6 @@ __global__ __launch_bounds__(256) void irradiance_rows_kernel(const char *env, i
         pair_sum[tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     __syncthreads();
-    const float nf = (float)env_n;
     for (int t0 = 0; t0 < IRR_GROUP;) {
         // the texels [t0, t1) whose rows fit the row buffer together
         int t1 = IRR_GROUP;
@@ -756,35 +852,16 @@ __global__ __launch_bounds__(256) void irradiance_rows_kernel(const char *env, i
             const float *fr = frame[t];
             const f3 N = mk3(fr[0], fr[1], fr[2]), right = mk3(fr[3], fr[4], fr[5]), up = mk3(fr[6], fr[7], fr[8]);
             const float2 pcs = phi_cs[a];
-            float sr = 0.0f, sg = 0.0f, sb = 0.0f;
-            int found = 0;
-            for (int b = bl; b <= bh; b++) {
-                const float2 tsc = theta_sc[b];
-                const float st = tsc.x, ct = tsc.y;
-                const float tx = st * pcs.x, ty = st * pcs.y, tz = ct;
-                // the direction in the face's coordinates; it lies on the face when cube_face would pick it (ties: z over y over x)
-                const float sc = fma_(tz, N.x, fma_(ty, up.x, tx * right.x));
-                const float tc = fma_(tz, N.y, fma_(ty, up.y, tx * right.y));
-                const float mj = fma_(tz, N.z, fma_(ty, up.z, tx * right.z));
-                const float asc = __builtin_fabsf(sc), atc = __builtin_fabsf(tc), ma = __builtin_fabsf(mj);
-                // the major axis wins a tie against an axis that cube_face looks at later (z, then y, then x) and loses it
-                // against one it looks at earlier
-                const bool over_s = sc_later ? ma >= asc : !(asc >= ma);
-                const bool over_t = tc_later ? ma >= atc : !(atc >= ma);
-                const bool side = positive ? mj >= 0.0f : !(mj <= 0.0f);
-                const float ima = rcp_rn_checked(ma);
-                const float s_ = fma_(sc * ima, 0.5f, 0.5f), t_ = fma_(tc * ima, 0.5f, 0.5f);
-                const float x = s_ * nf - 0.5f, y = t_ * nf - 0.5f;
-                const bool inside = x >= geo.x_lo && x < geo.x_hi && y >= geo.y_lo && y < geo.y_hi;
-                if ((over_s && over_t && side && inside) || every) {
-                    const f3 c = fetch_footprint_tile(face, env_n, tiles_per_side, x, y);
-                    sr = fma_(c.x * ct, st, sr);
-                    sg = fma_(c.y * ct, st, sg);
-                    sb = fma_(c.z * ct, st, sb);
-                    found++;
-                }
+            float4 sum;
+            switch (rf) {
+            case 0: sum = irr_walk_row<false, false, true>(walk, theta_sc, N, right, up, pcs, bl, bh, every); break;
+            case 1: sum = irr_walk_row<false, false, false>(walk, theta_sc, N, right, up, pcs, bl, bh, every); break;
+            case 2: sum = irr_walk_row<true, false, true>(walk, theta_sc, N, right, up, pcs, bl, bh, every); break;
+            case 3: sum = irr_walk_row<true, false, false>(walk, theta_sc, N, right, up, pcs, bl, bh, every); break;
+            case 4: sum = irr_walk_row<true, true, true>(walk, theta_sc, N, right, up, pcs, bl, bh, every); break;
+            default: sum = irr_walk_row<true, true, false>(walk, theta_sc, N, right, up, pcs, bl, bh, every); break;
             }
-            row_sum[q] = make_float4(sr, sg, sb, (float)found);
+            row_sum[q] = sum;
         }
         __syncthreads();
         {   // the rows of a pair in phi order, one lane per texel and channel (the fourth: the number of samples)

@@ -29,25 +29,73 @@ struct irr_v3 { float x, y, z; };
 VKR_HD irr_v3 irr_mk(float x, float y, float z) { irr_v3 r; r.x = x; r.y = y; r.z = z; return r; }
 VKR_HD float irr_dot(irr_v3 a, irr_v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 VKR_HD irr_v3 irr_cross(irr_v3 a, irr_v3 b) { return irr_mk(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x))); }
-VKR_HD irr_v3 irr_unit(irr_v3 a) { const float s = 1.0f / sqrtf(irr_dot(a, a)); return irr_mk(a.x * s, a.y * s, a.z * s); }
+// Reciprocal, reciprocal root and root: bounds need them to a few ulps only, so the device takes the hardware's
+// estimates (1 ulp) instead of the correctly rounded sequences; everything built on them is widened by IRR_MARGIN.
+#if defined(__HIP_DEVICE_COMPILE__)
+VKR_HD float irr_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+VKR_HD float irr_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+VKR_HD float irr_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+#else
+VKR_HD float irr_rcp(float x) { return 1.0f / x; }
+VKR_HD float irr_rsq(float x) { return 1.0f / sqrtf(x); }
+VKR_HD float irr_sqrt(float x) { return sqrtf(x); }
+#endif
+VKR_HD irr_v3 irr_unit(irr_v3 a) { const float s = irr_rsq(irr_dot(a, a)); return irr_mk(a.x * s, a.y * s, a.z * s); }
+
+// atan on [0, 1] to 1e-5 (Abramowitz & Stegun 4.4.49)
+VKR_HD float irr_atan_unit(float x)
+{
+    const float x2 = x * x;
+    return x * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 0.0208351f, -0.0851330f), 0.1801410f), -0.3302995f), 0.9998660f);
+}
+// atan on [0, inf] (reflected beyond 1) and atan2 in (-pi, pi], both to about 1e-5: enough for bounds that are widened
+// by IRR_MARGIN afterwards
+VKR_HD float irr_atan_pos(float t)
+{
+    const bool big = t > 1.0f;
+    const float p = irr_atan_unit(big ? irr_rcp(t) : t);
+    return big ? 0.5f * IRR_PI - p : p;
+}
+VKR_HD float irr_atan2(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    float p = mx > 0.0f ? irr_atan_unit(mn * irr_rcp(mx)) : 0.0f;
+    p = ay > ax ? 0.5f * IRR_PI - p : p;
+    p = x < 0.0f ? IRR_PI - p : p;
+    return y < 0.0f ? -p : p;
+}
+// sin on [0, 1.6] to 4e-6 (Taylor to x^9)
+VKR_HD float irr_sin_small(float x)
+{
+    const float x2 = x * x;
+    return x * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 2.7557319e-6f, -1.9841270e-4f), 8.3333333e-3f), -0.16666667f), 1.0f);
+}
+// the angle between two unit vectors, from the cross and the dot product: accurate near 0 and pi as well
+VKR_HD float irr_angle(irr_v3 a, irr_v3 b)
+{
+    const irr_v3 c = irr_cross(a, b);
+    return irr_atan2(irr_sqrt(irr_dot(c, c)), irr_dot(a, b));
+}
 
 // The box of (phi, theta) indices the rectangle spans as seen from N.  Polar angle: the farthest point of the
 // rectangle is a corner, the nearest lies on an edge (an arc of a great circle) or is N itself.  Azimuth: if N lies
 // outside, the rectangle spans less than half a turn, between the azimuths of two of its corners.  `slack` widens the
-// rectangle for the test "N inside" (in units of sc/ma).
+// rectangle for the test "N inside" (in units of sc/ma).  The angles come from the short approximations above
+// (a few 1e-5 rad in total against the 4e-3 of IRR_MARGIN).
 VKR_HD irr_box irr_pair_box(irr_v3 Nf, irr_v3 rightf, irr_v3 upf, float u0, float u1, float v0, float v1, float slack, int nphi, int ntheta)
 {
     const float us[4] = {u0, u1, u0, u1}, vs[4] = {v0, v0, v1, v1};
     irr_v3 corner[4];
     float th_max = 0.0f, th_corner[4];
     const irr_v3 centre = irr_mk(0.5f * (u0 + u1), 0.5f * (v0 + v1), 1.0f);
-    const float phc = atan2f(irr_dot(centre, upf), irr_dot(centre, rightf));
+    const float phc = irr_atan2(irr_dot(centre, upf), irr_dot(centre, rightf));
     float d_lo = 0.0f, d_hi = 0.0f;  // azimuth relative to the centre's
     for (int k = 0; k < 4; k++) {
         corner[k] = irr_unit(irr_mk(us[k], vs[k], 1.0f));
-        th_corner[k] = acosf(fminf(fmaxf(irr_dot(corner[k], Nf), -1.0f), 1.0f));
+        th_corner[k] = irr_angle(corner[k], Nf);
         th_max = fmaxf(th_max, th_corner[k]);
-        float d = atan2f(irr_dot(corner[k], upf), irr_dot(corner[k], rightf)) - phc;
+        float d = irr_atan2(irr_dot(corner[k], upf), irr_dot(corner[k], rightf)) - phc;
         d = d > IRR_PI ? d - 2.0f * IRR_PI : (d <= -IRR_PI ? d + 2.0f * IRR_PI : d);
         d_lo = fminf(d_lo, d); d_hi = fmaxf(d_hi, d);
     }
@@ -61,7 +109,8 @@ VKR_HD irr_box irr_pair_box(irr_v3 Nf, irr_v3 rightf, irr_v3 upf, float u0, floa
             const irr_v3 nrm = irr_unit(irr_cross(A, B));
             // the foot of the perpendicular from N lies on the arc when N is on the inner side of both end planes
             const bool on_arc = irr_dot(irr_cross(A, Nf), nrm) >= 0.0f && irr_dot(irr_cross(Nf, B), nrm) >= 0.0f;
-            const float d = on_arc ? asinf(fminf(fabsf(irr_dot(Nf, nrm)), 1.0f)) : fminf(th_corner[ea[e]], th_corner[eb[e]]);
+            const float h = fminf(fabsf(irr_dot(Nf, nrm)), 1.0f);  // sine of the distance to the arc's great circle
+            const float d = on_arc ? irr_atan2(h, irr_sqrt(fmaf(-h, h, 1.0f))) : fminf(th_corner[ea[e]], th_corner[eb[e]]);
             th_min = fminf(th_min, d);
         }
     }
@@ -74,7 +123,7 @@ VKR_HD irr_box irr_pair_box(irr_v3 Nf, irr_v3 rightf, irr_v3 upf, float u0, floa
     b1 = b1 > ntheta - 1 ? ntheta - 1 : b1;
     bx.nb = b1 - bx.b0 + 1;
     // IRR_MARGIN of arc is this much azimuth at the polar angle where the rectangle comes nearest to N
-    const float margin = IRR_MARGIN / fmaxf(sinf(th_min), 1e-6f);
+    const float margin = IRR_MARGIN * irr_rcp(fmaxf(irr_sin_small(fminf(th_min, 1.6f)), 1e-6f));
     bool full = n_inside || (d_hi - d_lo) + 2.0f * margin >= 2.0f * IRR_PI - 2.0f * IRR_STEP;
     if (!full) {
         const float centre_phi = phc < 0.0f ? phc + 2.0f * IRR_PI : phc;
@@ -126,8 +175,11 @@ struct irr_region_rect {
 };
 VKR_HD void irr_region_grid(int n, int *per_side, int *cells_per_region)
 {
+#ifndef VKR_IRR_REGION_CELLS
+#define VKR_IRR_REGION_CELLS 128
+#endif
     const int cells = n / 3 + 1;
-    *per_side = (cells + 127) / 128;
+    *per_side = (cells + VKR_IRR_REGION_CELLS - 1) / VKR_IRR_REGION_CELLS;
     *cells_per_region = (cells + *per_side - 1) / *per_side;
 }
 VKR_HD irr_region_rect irr_region_geometry(int n, int per_side, int cells_per_region, int rx, int ry)
@@ -146,16 +198,6 @@ VKR_HD irr_region_rect irr_region_geometry(int n, int per_side, int cells_per_re
     return g;
 }
 
-// atan on [0, inf] to about 1e-5 (Abramowitz & Stegun 4.4.49 on [0, 1], reflected beyond); enough for a bound that
-// is widened by IRR_MARGIN afterwards
-VKR_HD float irr_atan_pos(float t)
-{
-    const bool big = t > 1.0f;
-    const float x = big ? 1.0f / t : t, x2 = x * x;
-    const float p = x * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 0.0208351f, -0.0851330f), 0.1801410f), -0.3302995f), 0.9998660f);
-    return big ? 0.5f * IRR_PI - p : p;
-}
-
 // The theta indices of phi row (cp, sp) = (cos phi_a, sin phi_a) whose samples can land in the rectangle
 // U0 <= sc/ma <= U1, V0 <= tc/ma <= V1 (the caller passes the rectangle widened by what its own coordinate
 // rounding can amount to).  Along the row d = sin(theta) e + cos(theta) N with e = cp right + sp up, and each side
@@ -169,7 +211,9 @@ VKR_HD void irr_row_interval(irr_v3 Nf, irr_v3 rightf, irr_v3 upf, float cp, flo
     float lo = 0.0f, hi = INFINITY;
     bool none = false;
     for (int k = 0; k < 4; k++) {
-        const float q = -B[k] / A[k];  // NaN (0/0) is dropped by fmaxf / fminf: no constraint
+        // NaN (0 x inf) is dropped by fmaxf / fminf: no constraint; a relative error of 2^-22 in tan(theta) moves theta by
+        // less than 2^-22 rad
+        const float q = -B[k] * irr_rcp(A[k]);
         if (A[k] > 0.0f) lo = fmaxf(lo, q);
         else if (A[k] < 0.0f) hi = fminf(hi, q);
         else if (B[k] < 0.0f) none = true;

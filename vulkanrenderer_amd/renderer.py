@@ -229,7 +229,9 @@ class HipRenderer:
         assert a.dtype == np.uint16 and a.shape == (6, self.env_res, self.env_res, 4)
         self._call(self._lib.vkr_upload_env_cube, _host_ptr(a))
 
-    def CreateIrradianceCubemap(self, order: int = _lib.IRRADIANCE_SEQUENTIAL) -> None:
+    def CreateIrradianceCubemap(self, order: int = _lib.IRRADIANCE_FASTEST) -> None:
+        """VulkanRenderer.cs:734.  The default order is the library's fastest (by region of the environment with row sums),
+        which differs from the shader's own running sum (IRRADIANCE_SEQUENTIAL) in rounding only."""
         self._call(self._lib.vkr_create_irradiance_cubemap, order)
 
     def CreatePrefilteredCubemap(self) -> None:
