@@ -259,6 +259,47 @@ def phase_times(renderer, dev_frame, world: int, steps: int, device) -> dict:
     return {n: round(float(v), 4) for n, v in zip(names, t.tolist())}
 
 
+# what the prediction below assumes of the fabric between GPUs (nothing here can measure it: the development box has
+# one GPU): a point-to-point message of a few hundred KiB between neighbours, and the rate of one xGMI link
+XGMI_SMALL_MESSAGE_MS = 0.03
+XGMI_LINK_GBS = 50.0
+
+
+def predict_strong_scaling(whole, scene_dev, width: int, height: int, worlds, steps: int, device) -> dict:
+    """Frame times at `worlds` GPUs predicted from this one GPU: every strip of an N-way split is rendered here, alone,
+    in a steady loop (composition + post chain, the clamped form: a strip without neighbours costs what one with halo
+    rows costs); the slowest strip sets the frame, the halo exchange is priced at one small message that the interior
+    rows do not hide, and the RGBA8 gather on rank 0 at N - 1 links' rate (it overlaps the next frame when two frames
+    are in flight, so it is listed and not added).  Unmeasured on hardware: a figure to hold the first N-GPU run against."""
+    import torch
+    from vulkanrenderer_amd.strips import StripPlan, StripRenderer
+    out = {}
+    for n in worlds:
+        per_strip = []
+        for k in range(n):
+            plan = StripPlan.make(k, n, height)
+            frame = strip_device_frame(scene_dev, whole.rows(plan.row0, plan.row0 + plan.rows), 0, plan.rows, device)
+            r = StripRenderer(StripPlan.make(0, 1, plan.rows), width, device=device, frames_in_flight=2)
+            per_strip.append(timed_frames(r, frame, 1, steps, 2, device) / steps * 1e3)
+            del r, frame
+        torch.cuda.empty_cache()
+        slowest = max(per_strip)
+        halo = XGMI_SMALL_MESSAGE_MS if n > 1 else 0.0
+        gather_bytes = width * height * 4 * (n - 1) // n
+        gather = gather_bytes / (XGMI_LINK_GBS * 1e9 * max(min(n - 1, 7), 1)) * 1e3 + (XGMI_SMALL_MESSAGE_MS if n > 1 else 0.0)
+        ms = slowest + halo
+        out[str(n)] = {"strip_rows": height // n, "strip_ms_slowest": round(slowest, 4), "strip_ms_mean": round(sum(per_strip) / n, 4),
+                       "halo_ms_assumed": halo, "gather_ms_at_link_rate_overlapped": round(gather, 4),
+                       "predicted_ms_per_frame": round(ms, 4), "predicted_Mpixels/s": round(width * height / (ms * 1e-3) / 1e6, 1)}
+    base = out.get("1", {}).get("predicted_ms_per_frame")
+    if base:
+        for n, rec in out.items():
+            rec["predicted_speedup"] = round(base / rec["predicted_ms_per_frame"], 2)
+    out["note"] = ("predicted from single-GPU strip timings, unmeasured on hardware; assumes "
+                   f"{XGMI_SMALL_MESSAGE_MS} ms per neighbour message and {XGMI_LINK_GBS:g} GB/s per xGMI link")
+    return out
+
+
 def kernel_times(renderer, dev_frame, rows: int, steps: int) -> dict:
     """Average duration of the two kernels of a step (shade; both bloom passes + post-process as one kernel), each
     between two HIP events on the launch stream, and of the three-pass form of the post chain the one kernel
@@ -328,27 +369,24 @@ def time_ibl(device, reps: int = 3) -> tuple[dict, list]:
     def run():
         """The precompute as a renderer runs it: the irradiance pass in the library's default order (by region of the
         environment with row sums, from footprint tiles)."""
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
         ev[0].record()
         P.equirect_to_cube(src, _lib.SRC_RGBA16F, env)
         ev[1].record()
-        box["tiled"] = P.tile_env_cube(env)  # the copy the prefilter passes read
+        box["foot"] = P.tile_env_footprints(env)  # the copy the irradiance and prefilter passes read
         ev[2].record()
-        box["foot"] = P.tile_env_footprints(env)  # the copy the irradiance pass reads
-        ev[3].record()
         box["ws"] = P.irradiance_by_region_rows(box["foot"], 2048, irr, workspace=box.get("ws"))
+        ev[3].record()
+        P.prefilter_mips(box["foot"], pres, env_layout=_lib.ENV_LAYOUT_FOOTPRINT_TILES, env_n=2048)  # mip 0, then mips 1-4 in one launch
         ev[4].record()
-        for m in range(5):
-            P.prefilter(box["tiled"], pres[m], m / 4.0, env_layout=_lib.ENV_LAYOUT_TILED_4X4)
-            ev[5 + m].record()
         P.brdf_lut(lut)
-        ev[10].record()
+        ev[5].record()
         torch.cuda.synchronize()
-        return [ev[i].elapsed_time(ev[i + 1]) for i in range(10)]
+        return [ev[i].elapsed_time(ev[i + 1]) for i in range(5)]
 
     run()
     t = np.mean([run() for _ in range(reps)], axis=0)
-    eq, tile, foot, irr_ms, pre_ms, lut_ms = t[0], t[1], t[2], t[3], t[4:9], t[9]
+    eq, foot, irr_ms, pre_total, lut_ms = t
     uncovered = P.irradiance_uncovered(box["ws"])
 
     def timed(fn):
@@ -361,6 +399,11 @@ def time_ibl(device, reps: int = 3) -> tuple[dict, list]:
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
 
+    # the prefilter mips one launch each (what the per-mip roofline records are made from), from both tiled layouts
+    box["tiled"] = P.tile_env_cube(env)
+    tile = timed(lambda: P.tile_env_cube(env))
+    pre_ms = np.array([timed(lambda: P.prefilter(box["foot"], pres[m], m / 4.0, env_layout=_lib.ENV_LAYOUT_FOOTPRINT_TILES, env_n=2048)) for m in range(5)])
+    pre_ms_4x4 = np.array([timed(lambda: P.prefilter(box["tiled"], pres[m], m / 4.0, env_layout=_lib.ENV_LAYOUT_TILED_4X4)) for m in range(5)])
     # beside it: the shader's own summation order (one running sum per texel), and the first by-region order
     seq_ms = timed(lambda: P.irradiance(box["tiled"], irr_seq, _lib.IRRADIANCE_SEQUENTIAL, env_layout=_lib.ENV_LAYOUT_TILED_4X4))
     ws2 = P.irradiance_by_region(box["tiled"], irr_reg, env_layout=_lib.ENV_LAYOUT_TILED_4X4)
@@ -376,16 +419,19 @@ def time_ibl(device, reps: int = 3) -> tuple[dict, list]:
     orders = {"by_region_rows (default, timed in total_ms)": {"irradiance_ms": round(float(irr_ms), 3), "footprint_tiles_ms": round(float(foot), 3),
                                                               "workspace_bytes": int(box["ws"].numel()), "footprint_tile_bytes": int(box["foot"].numel()),
                                                               "texels_with_samples_unaccounted_for": uncovered, "against_the_shader_order": against_shader_order(irr)},
-              "sequential (the shader's running sum)": {"irradiance_ms": round(float(seq_ms), 3), "total_ms": round(float(t.sum() - irr_ms - foot + seq_ms), 3)},
-              "by_region": {"irradiance_ms": round(float(region_ms), 3), "total_ms": round(float(t.sum() - irr_ms - foot + region_ms), 3),
+              "sequential (the shader's running sum)": {"irradiance_ms": round(float(seq_ms), 3), "total_ms": round(float(t.sum() - irr_ms + seq_ms + tile), 3)},
+              "by_region": {"irradiance_ms": round(float(region_ms), 3), "total_ms": round(float(t.sum() - irr_ms + region_ms + tile), 3),
                             "texels_with_samples_unaccounted_for": P.irradiance_uncovered(ws2), "against_the_shader_order": against_shader_order(irr_reg)},
               "note": "every order is bit-exact against its own restatement in oracle/ (orc_irradiance, order 0 / 2 / 3); the by-region orders add the same "
                       "15 876 samples per texel in another order and stay within one binary16 ulp of the shader's"}
-    stages = {"equirect_ms": round(float(eq + tile + foot), 3), "irradiance_ms": round(float(irr_ms), 3), "prefilter_ms": round(float(pre_ms.sum()), 3),
+    stages = {"equirect_ms": round(float(eq + foot), 3), "irradiance_ms": round(float(irr_ms), 3), "prefilter_ms": round(float(pre_total), 3),
               "brdf_lut_ms": round(float(lut_ms), 3), "total_ms": round(float(t.sum()), 3),
-              "total_ms_with_the_shader_summation_order": round(float(t.sum() - irr_ms - foot + seq_ms), 3),
-              "config": "equirect 4096x2048 RGBA16F -> env 2048^2 (+ 4x4-tiled copy for the prefilter, footprint-tile copy for the irradiance pass), "
-                        "irradiance 64^2 in the library's default order (VKR_IRRADIANCE_BY_REGION_ROWS), prefilter 128^2 x5 mips, LUT 512^2",
+              "total_ms_with_the_shader_summation_order": round(float(t.sum() - irr_ms + seq_ms + tile), 3),
+              "config": "equirect 4096x2048 RGBA16F -> env 2048^2 (+ its copy in footprint tiles, which the irradiance and prefilter passes read), "
+                        "irradiance 64^2 in the library's default order (VKR_IRRADIANCE_BY_REGION_ROWS), prefilter 128^2 x5 mips in two launches "
+                        "(mip 0; mips 1-4 together), LUT 512^2",
+              "prefilter_launch_per_mip_ms": {"footprint_tiles": [round(float(v), 4) for v in pre_ms], "sum": round(float(pre_ms.sum()), 4),
+                                              "tiles_4x4": [round(float(v), 4) for v in pre_ms_4x4], "sum_4x4": round(float(pre_ms_4x4.sum()), 4)},
               "irradiance_orders": orders}
 
     def valu(kernel, ops, ms, algorithmic, **more):
@@ -427,8 +473,8 @@ def time_ibl(device, reps: int = 3) -> tuple[dict, list]:
         n = 128 >> m
         roof.append(valu(f"prefilter_texel_kernel mip {m} (roughness {m / 4:g})", OPS_PREFILTER_SAMPLE * GGX_SAMPLES * 6 * n * n, pre_ms[m],
                          f"{OPS_PREFILTER_SAMPLE} FP32 ops x {GGX_SAMPLES} samples x {6 * n * n} texels"))
-    roof.append(valu("prefilter_texel_kernel, 5 mips", OPS_PREFILTER_SAMPLE * GGX_SAMPLES * sum(6 * (128 >> m) ** 2 for m in range(5)), pre_ms.sum(),
-                     f"{OPS_PREFILTER_SAMPLE} FP32 ops x {GGX_SAMPLES} samples x 130944 texels, five launches"))
+    roof.append(valu("prefilter_texel_kernel, 5 mips", OPS_PREFILTER_SAMPLE * GGX_SAMPLES * sum(6 * (128 >> m) ** 2 for m in range(5)), pre_total,
+                     f"{OPS_PREFILTER_SAMPLE} FP32 ops x {GGX_SAMPLES} samples x 130944 texels, two launches (mip 0; mips 1-4 together) as the precompute runs them"))
     roof.append(valu("brdf_lut_kernel", OPS_BRDF_SAMPLE * GGX_SAMPLES * lut_texels, lut_ms,
                      f"{OPS_BRDF_SAMPLE} FP32 ops x {GGX_SAMPLES} samples x {lut_texels} texels"))
     return stages, roof
@@ -472,7 +518,7 @@ def time_coverage(f, dev_frame, renderer, device) -> dict:
     import torch
     from vulkanrenderer_amd import passes as P, synth
 
-    verts, tris = synth.make_sphere_mesh()
+    verts, tris = synth.reference_light_volume()
     dverts, dtris = torch.from_numpy(verts).to(device), torch.from_numpy(tris.astype(np.int32)).to(device)
 
     def timed(fn, reps=10):
@@ -517,7 +563,7 @@ def time_coverage(f, dev_frame, renderer, device) -> dict:
                            "shade_ms": round(timed(lambda: P.shade(small, color, thr)), 4),
                            "covered_fraction": round(frac, 4),
                            "note": "same lights with colours x0.02: volume radius 16*sqrt(max/5) shrinks to ~1-2.5 units"}
-    out["mesh"] = f"UV sphere, {len(verts)} vertices, {len(tris)} triangles (the reference volume's topology)"
+    out["mesh"] = f"the reference's light volume (assets/models/sphere/sphere.glb as arrays, tests/golden/light_volume.npz): {len(verts)} vertices, {len(tris)} triangles"
     return out
 
 
@@ -555,7 +601,7 @@ def time_shadow_pass(f, dev_frame, device) -> dict:
     # whole frame, and for the rows one rank of eight owns (every rank renders all shadow maps: that part does not shrink).
     import dataclasses
     from vulkanrenderer_amd.strips import HALO, HipBackend, StripPlan
-    sv, st = synth.make_sphere_mesh()
+    sv, st = synth.reference_light_volume()
     volume = (torch.from_numpy(sv).to(device), torch.from_numpy(st.astype(np.int32)).to(device))
     be = HipBackend(device)
 
@@ -687,6 +733,7 @@ def main() -> None:
     ap.add_argument("--no-extra", action="store_true", help="N > 1: skip the extra shapes (a full strip per rank and the 16384-wide / 256-light strip)")
     ap.add_argument("--extra", action="store_true", help="N = 1: also time the 16384x2048 / 256-light strip (off by default, so that every launch of the "
                     "shading kernel in a default run has the shape the roofline is quoted on and a kernel trace of the run averages one shape)")
+    ap.add_argument("--no-predict", action="store_true", help="skip the predicted strong-scaling table (every strip of the 1/2/4/8-way splits rendered alone)")
     ap.add_argument("--transport-only", action="store_true", help="rehearse launcher, halo exchange and gather on CPU tensors (no GPU, no kernels)")
     ap.add_argument("--launch-timeout", type=float, default=900.0, help="seconds the self-started ranks may take")
     args = ap.parse_args()
@@ -852,6 +899,11 @@ def main() -> None:
     }
     if world > 1:
         out["gathered_equals_single_gpu"] = gathered_ok
+    if not args.no_predict:
+        # N = 1: the curve for 1, 2, 4, 8 GPUs; N > 1: this N, to hold beside the measured phases above
+        note("strips of the N-way splits rendered alone (prediction)")
+        out["predicted_strong_scaling"] = predict_strong_scaling(whole, dev_frame, WIDTH, HEIGHT, (1, 2, 4, 8) if world == 1 else (1, world),
+                                                                 max(args.steps // 2, 3), device)
     out.update(extra)
     if world == 1 and dev_frame.cube_layout != 0:
         rt = time_shadow_retile(f, device)

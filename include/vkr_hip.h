@@ -181,7 +181,10 @@ typedef struct VkrCoverageArgs {
                                      provably covers every pixel (the camera sees every triangle of the closed mesh from
                                      behind and every triangle a pixel ray can hit lies between the near and the far
                                      plane): such a light's masks are written as all ones without rasterising anything.
-                                     Word n_lights becomes the number of lights whose word is 0. */
+                                     Word n_lights becomes the number of lights whose word is 0.  Pass it for a CLOSED mesh
+                                     only (every edge shared by two triangles of opposite direction): the conclusion rests
+                                     on back faces alone, and an open volume seen from inside would be taken to cover the
+                                     frame.  Layer 2 checks the mesh in vkr_set_light_volume_mesh and passes NULL otherwise. */
 } VkrCoverageArgs;
 VKR_EXPORT int32_t vkr_light_coverage(const VkrCoverageArgs *args, void *stream);
 
@@ -353,6 +356,20 @@ VKR_EXPORT int32_t vkr_ibl_irradiance_by_region(const void *env, int32_t env_n, 
  * found is also written as NaN (by both calls).  Neither call has a counterpart in the reference beyond the pass itself. */
 VKR_EXPORT int64_t vkr_env_footprint_tiles_bytes(int32_t n);
 VKR_EXPORT int32_t vkr_tile_rgba16f_footprints(const void *linear_cube, void *tiles, int32_t n, void *stream);
+/* All roughness mips of the prefiltered cube in as few launches as serve them best (mips too small to fill the chip
+ * alone share one): VulkanRenderer.cs:855-884, roughness of mip m = m / (mips - 1) (:874).  out[m]: the RGBA16F cube of
+ * mip m, face size base_res >> m; rows [row_begin[m], row_end[m]) of its 6 * (base_res >> m) rows are computed.  The
+ * images equal those of one vkr_ibl_prefilter call per mip.  env_layout: any VKR_ENV_LAYOUT_* (footprint tiles: `env`
+ * is the buffer vkr_tile_rgba16f_footprints filled, env_res the face size of the cube it was made from). */
+#define VKR_PREFILTER_MAX_MIPS 8
+typedef struct VkrPrefilterMipsArgs {
+    const void *env; int32_t env_res, env_layout;
+    int32_t base_res, mips;
+    void *out[VKR_PREFILTER_MAX_MIPS];
+    int32_t row_begin[VKR_PREFILTER_MAX_MIPS], row_end[VKR_PREFILTER_MAX_MIPS];
+} VkrPrefilterMipsArgs;
+VKR_EXPORT int32_t vkr_ibl_prefilter_mips(const VkrPrefilterMipsArgs *args, void *stream);
+
 VKR_EXPORT int64_t vkr_ibl_irradiance_by_region_rows_workspace_bytes(int32_t env_n, int32_t n, int32_t row_begin, int32_t row_end);
 VKR_EXPORT int32_t vkr_ibl_irradiance_by_region_rows(const void *env_tiles, int32_t env_n, void *out, int32_t n,
                            int32_t row_begin, int32_t row_end, void *workspace, int64_t workspace_bytes, void *stream);

@@ -33,7 +33,7 @@ else:
     d = P.DeviceFrame.upload(f, dev)
 color = torch.empty((bench.HEIGHT, bench.WIDTH, 4), dtype=torch.float16, device=dev)
 thr = torch.empty_like(color)
-verts, tris = synth.make_sphere_mesh()
+verts, tris = synth.reference_light_volume()
 dverts, dtris = torch.from_numpy(verts).to(dev), torch.from_numpy(tris.astype(np.int32)).to(dev)
 forms = {"plain": d}
 if not os.environ.get("VKR_C5"):

@@ -11,7 +11,7 @@ from tests.test_gpu_parity import _gpass_scene, _camera_scene
 w, h, nl, n_strips = 640, 360, 6, 3
 draws = _gpass_scene(w, h)
 lights = [synth.make_lights(np.random.default_rng(6 + k), nl) for k in range(5)]
-sphere = synth.make_sphere_mesh()
+sphere = synth.reference_light_volume()
 env = synth.make_env_cube(np.random.default_rng(2), 16)
 kw = dict(max_lights=8, dir_shadow_res=128, point_shadow_res=64, env_res=16, irradiance_res=8, prefilter_res=16, prefilter_mips=1, brdf_lut_res=32)
 plans = [strip_plan(h, n_strips, k) for k in range(n_strips)]

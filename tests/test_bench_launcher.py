@@ -24,7 +24,7 @@ def _json_line(stdout: str) -> dict:
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("world,height", [(2, 97), (3, 41)])
+@pytest.mark.parametrize("world,height", [(2, 97), (3, 41), (8, 97)])
 def test_self_launched_ranks_exchange_halos_and_gather(world, height):
     p = _run("--gpus", str(world), "--transport-only", "--steps", "2", "--warmup", "1", "--height", str(height))
     assert p.returncode == 0, p.stderr[-2000:]
@@ -68,3 +68,21 @@ def test_self_launched_ranks_render_one_frame_in_strips(gpu):
     assert orders["by_region"]["texels_with_samples_unaccounted_for"] == 0
     assert orders["by_region_rows (default, timed in total_ms)"]["against_the_shader_order"]["max_difference_binary16_ulps"] <= 1.0
     assert line["ibl_precompute"]["total_ms"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(420)
+def test_eight_ranks_render_the_headline_frame_in_strips(gpu):
+    """The headline frame itself -- 3840 x 2160, 64 lights with 1024^2 cubes, a 4096^2 directional map -- cut into the
+    eight 270-row strips of an 8-GPU run, the eight ranks sharing cuda:0 over gloo: the launcher, the halo exchange
+    between seven neighbour pairs and the gather of eight strips at full size, and the gathered image equals the image
+    rank 0 renders alone, byte for byte.  (RCCL itself needs eight GPUs; the transport is the only thing that differs.)"""
+    p = _run("--gpus", "8", "--steps", "2", "--warmup", "1", "--no-extra", "--no-ibl", "--no-predict", "--launch-timeout", "360",
+             env={"VKR_DIST_BACKEND": "gloo"}, timeout=400)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = _json_line(p.stdout)
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong"
+    assert line["distributed"]["backend"] == "gloo" and line["distributed"]["world"] == 8
+    assert "8 strips of 270 rows" in line["config"]["workload"] and "3840x2160" in line["config"]["workload"]
+    assert line["gathered_equals_single_gpu"] is True
+    assert line["value"] > 0

@@ -86,7 +86,12 @@ def test_shade_against_reference_shader_vectors(gpu, fixture):
     close = lambda a, b: np.abs(a - b) <= np.maximum(1e-3, 2.0 * f16_ulp(b))
     assert close(got_c, g["color"]).all(), f"colour: max abs diff {np.abs(got_c - g['color']).max()}"
     sure = ~g["near_threshold"]
+    assert sure.mean() > 0.99   # the exclusion is a handful of pixels (0 of 192 and 1 of 1536 in the two fixtures), not a loophole
     assert close(got_t, g["threshold"])[sure].all()
+    # cleared texels: what light.frag.spv yields where max() of a NaN returns the other operand (exactly 0 per draw)
+    assert (g["cleared_light_out_max_is_maxnum"] == 0.0).all()
+    for _, y, x in g["cleared_px"]:
+        assert (got_c[y, x] == 0.0).all() and (got_t[y, x] == 0.0).all()
 
 
 def test_post_chain_and_ibl_against_reference_shader_vectors(gpu):
@@ -141,6 +146,78 @@ def test_post_chain_and_ibl_against_reference_shader_vectors(gpu):
     lut = torch.empty((ln, ln, 2), dtype=torch.float16, device=gpu)
     P.brdf_lut(lut)
     assert close(lut.float().cpu().numpy(), g["brdf_lut"]).all()
+
+
+def test_ibl_kernels_against_reference_shader_vectors_on_1024_faces(gpu):
+    """The four IBL kernels against the reference's .frag.spv on an environment with an interior (tests/golden/ibl_1024.npz):
+    all four irradiance summation orders, the row-major and both tiled environment layouts, the prefilter at its five
+    roughnesses, a 32^2 LUT, the equirect pass -- the recorded shader outputs directly, without the oracle in between."""
+    import os
+    from tests.test_golden_reference_spirv import _env_1024
+    torch, P = _torch(), _passes()
+    close = lambda a, b, ulps=2.0: np.abs(a - b) <= np.maximum(1e-3, ulps * f16_ulp(b))
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ibl_1024.npz"))
+    env = P.to_device_f16(_env_1024(g), gpu)
+    tiled = P.tile_env_cube(env)
+    n = int(g["irradiance_n"])
+    irr = torch.empty((6, n, n, 4), dtype=torch.float16, device=gpu)
+    cases = [(order, env, _lib.ENV_LAYOUT_LINEAR) for order in (_lib.IRRADIANCE_SEQUENTIAL, _lib.IRRADIANCE_PHI_SLICES, _lib.IRRADIANCE_BY_REGION,
+                                                               _lib.IRRADIANCE_BY_REGION_ROWS, _lib.IRRADIANCE_FASTEST)]
+    cases += [(order, tiled, _lib.ENV_LAYOUT_TILED_4X4) for order in (_lib.IRRADIANCE_SEQUENTIAL, _lib.IRRADIANCE_BY_REGION)]
+    for order, cube, layout in cases:
+        irr.zero_()
+        P.irradiance(cube, irr, order, env_layout=layout)   # the rows order makes its footprint tiles from the row-major cube
+        got = irr.float().cpu().numpy()
+        for (f, i, j), want in zip(g["irradiance_texels"], g["irradiance"]):
+            assert close(got[f, j, i], want).all(), (order, layout, f, i, j, got[f, j, i], want)
+    pn, pref = int(g["prefilter_n"]), {}
+    for (r, f, i, j), want in zip(g["prefilter_cases"], g["prefilter"]):
+        r = float(r)
+        for layout, cube in ((_lib.ENV_LAYOUT_LINEAR, env), (_lib.ENV_LAYOUT_TILED_4X4, tiled)):
+            if (r, layout) not in pref:
+                out = torch.empty((6, pn, pn, 4), dtype=torch.float16, device=gpu)
+                P.prefilter(cube, out, r, env_layout=layout)
+                pref[(r, layout)] = out.float().cpu().numpy()
+            assert close(pref[(r, layout)][int(f), int(j), int(i)], want).all(), (r, layout, f, i, j)
+    ln = g["brdf_lut"].shape[0]
+    lut = torch.empty((ln, ln, 2), dtype=torch.float16, device=gpu)
+    P.brdf_lut(lut)
+    assert close(lut.float().cpu().numpy(), g["brdf_lut"]).all()
+    en = g["equirect_cube"].shape[1]
+    cube = torch.empty((6, en, en, 4), dtype=torch.float16, device=gpu)
+    P.equirect_to_cube(P.to_device_f16(g["equirect_src"], gpu), _lib.SRC_RGBA16F, cube)
+    assert close(cube.float().cpu().numpy(), g["equirect_cube"]).all()
+
+
+@pytest.mark.parametrize("env_n,base,mips", [(64, 16, 5), (36, 12, 3), (128, 128, 2)])
+def test_prefilter_mips_in_one_call_equal_one_launch_per_mip(gpu, oracle, env_n, base, mips):
+    """vkr_ibl_prefilter_mips (the small mips share a launch, a large one takes sixteen texels per workgroup) against one
+    vkr_ibl_prefilter call per mip and against the oracle, from all three environment layouts, whole images and row
+    ranges as a rank of a sharded precompute passes them."""
+    torch, P = _torch(), _passes()
+    env = synth.make_env_cube(np.random.default_rng(77), env_n, sun_peak=8.0)
+    dev = P.to_device_f16(env, gpu)
+    layouts = [(dev, _lib.ENV_LAYOUT_LINEAR, None), (P.tile_env_footprints(dev), _lib.ENV_LAYOUT_FOOTPRINT_TILES, env_n)]
+    if env_n % 4 == 0:
+        layouts.append((P.tile_env_cube(dev), _lib.ENV_LAYOUT_TILED_4X4, None))
+    want = [oracle.prefilter(env, base >> m, m / max(mips - 1, 1)) for m in range(mips)]
+    for cube, layout, n_arg in layouts:
+        outs = [torch.zeros((6, base >> m, base >> m, 4), dtype=torch.float16, device=gpu) for m in range(mips)]
+        P.prefilter_mips(cube, outs, env_layout=layout, env_n=n_arg)
+        for m in range(mips):
+            assert_bits_equal(P.f16_bits(outs[m]), want[m], f"mip {m} of {mips}, layout {layout}")
+            one = torch.zeros_like(outs[m])
+            P.prefilter(cube, one, m / max(mips - 1, 1), env_layout=layout, env_n=n_arg)
+            assert torch.equal(one, outs[m])
+        # rows [1/3, 2/3) of every mip, the rest untouched
+        part = [torch.full((6, base >> m, base >> m, 4), 7.0, dtype=torch.float16, device=gpu) for m in range(mips)]
+        rows = [(2 * (base >> m), 4 * (base >> m)) for m in range(mips)]
+        P.prefilter_mips(cube, part, rows, env_layout=layout, env_n=n_arg)
+        for m in range(mips):
+            n = base >> m
+            got = P.f16_bits(part[m]).reshape(6 * n, n, 4)
+            assert np.array_equal(got[rows[m][0]:rows[m][1]], want[m].reshape(6 * n, n, 4)[rows[m][0]:rows[m][1]])
+            assert (part[m].reshape(6 * n, n, 4)[:rows[m][0]] == 7.0).all() and (part[m].reshape(6 * n, n, 4)[rows[m][1]:] == 7.0).all()
 
 
 def test_shade_background_image(gpu, oracle):
@@ -846,7 +923,7 @@ def test_light_coverage_masks_bit_exact(gpu, oracle, w, h, row0, frame_rows):
     """vkr_light_coverage against the oracle's rasterisation: volumes in front of, around and behind
     the camera, partly off screen, one beyond the far plane; whole frames and a strip of a frame."""
     torch, P = _torch(), _passes()
-    verts, tris = synth.make_sphere_mesh()
+    verts, tris = synth.reference_light_volume()
     f = synth.make_frame(61, w, h, 9, 16, 64, irr_res=8, pref_res=16, lut_res=32)
     f.scene = _camera_scene((2.0, 1.0, -4.0), aspect=w / frame_rows)
     f.lights = _small_lights(np.random.default_rng(5), 9, 0.01)
@@ -873,7 +950,7 @@ def test_light_coverage_flags_name_only_lights_that_cover_every_pixel(gpu, oracl
     view; wherever a word is set the oracle's rasterisation has every pixel covered, and the masks written with the
     words equal the oracle's bit for bit (ragged widths and a strip included: bits beyond the image stay clear)."""
     torch, P = _torch(), _passes()
-    verts, tris = synth.make_sphere_mesh()
+    verts, tris = synth.reference_light_volume()
     cam = (2.0, 1.0, -4.0)
     cases = [(cam, 8.0),                      # camera at the centre
              ((3.0, 2.0, -2.0), 12.0),        # camera well inside
@@ -907,7 +984,7 @@ def test_shade_skips_the_masks_when_every_light_covers_every_pixel(gpu, oracle):
     ones, and the shaded images equal the ones shaded without masks, whether or not the words are passed on."""
     torch, P = _torch(), _passes()
     w, h, nl = 176, 104, 7
-    verts, tris = synth.make_sphere_mesh()
+    verts, tris = synth.reference_light_volume()
     dverts, dtris = torch.from_numpy(verts).to(gpu), torch.from_numpy(tris.astype(np.int32)).to(gpu)
     f = synth.make_frame(62, w, h, nl, 32, 128, irr_res=8, pref_res=16, lut_res=32)
     f.scene = _camera_scene((2.0, 1.0, -4.0), aspect=w / h)
@@ -945,7 +1022,7 @@ def test_shade_with_light_volume_coverage(gpu, oracle):
     volume contains the camera."""
     torch, P = _torch(), _passes()
     w, h, nl = 176, 104, 7
-    verts, tris = synth.make_sphere_mesh()
+    verts, tris = synth.reference_light_volume()
     dverts, dtris = torch.from_numpy(verts).to(gpu), torch.from_numpy(tris.astype(np.int32)).to(gpu)
     f = synth.make_frame(62, w, h, nl, 32, 128, irr_res=8, pref_res=16, lut_res=32)
     f.scene = _camera_scene((2.0, 1.0, -4.0), aspect=w / h)
@@ -979,7 +1056,7 @@ def test_renderer_with_light_volume_mesh(gpu, oracle):
     chain shaded under the oracle's masks; order errors without a mesh."""
     from vulkanrenderer_amd.renderer import HipRenderer
     w, h, nl = 136, 88, 5
-    verts, tris = synth.make_sphere_mesh()
+    verts, tris = synth.reference_light_volume()
     f = synth.make_frame(71, w, h, nl, 16, 64, irr_res=8, pref_res=16, lut_res=32)
     f.scene = _camera_scene((2.0, 1.0, -4.0), aspect=w / h)
     f.lights = _small_lights(np.random.default_rng(3), nl, 0.03)
@@ -1234,7 +1311,7 @@ def test_renderer_renders_a_frame_from_draw_calls_only(gpu, oracle):
     f = synth.make_frame(78, w, h, nl, 32, 64, irr_res=8, pref_res=16, lut_res=32)
     f.scene = _camera_scene((2.0, 1.6, -4.0), aspect=w / h)
     f.lights = _small_lights(np.random.default_rng(6), nl, 0.05)
-    sphere = synth.make_sphere_mesh()
+    sphere = synth.reference_light_volume()
     with HipRenderer(w, h, max_lights=4, dir_shadow_res=64, point_shadow_res=32, env_res=16,
                      irradiance_res=8, prefilter_res=16, prefilter_mips=1, brdf_lut_res=32) as r:
         env = synth.make_env_cube(np.random.default_rng(2), 16)
@@ -1290,7 +1367,7 @@ def test_strip_contexts_of_one_process_equal_one_context(gpu, oracle, n_strips):
     # one light set per frame: bright ones (bloom to spread across the cuts) and small volumes (masks) in turn
     lights = [synth.make_lights(np.random.default_rng(6 + k), nl) if k % 2 == 0 else _small_lights(np.random.default_rng(6 + k), nl, 0.3) for k in range(4)]
     bloom_seen = 0
-    sphere = synth.make_sphere_mesh()
+    sphere = synth.reference_light_volume()
     env = synth.make_env_cube(np.random.default_rng(2), 16)
     kw = dict(max_lights=4, dir_shadow_res=64, point_shadow_res=32, env_res=16, irradiance_res=8, prefilter_res=16, prefilter_mips=1, brdf_lut_res=32)
     plans = [strip_plan(h, n_strips, k) for k in range(n_strips)]
@@ -1619,7 +1696,7 @@ def test_renderer_end_frame_takes_the_lights_list_and_the_volume_mesh(gpu, oracl
     import dataclasses
     from vulkanrenderer_amd.renderer import Light
     w, h, nl = 136, 88, 5
-    verts, tris = synth.make_sphere_mesh()
+    verts, tris = synth.reference_light_volume()
     f = synth.make_frame(72, w, h, nl, 16, 64, irr_res=8, pref_res=16, lut_res=32)
     f.scene = _camera_scene((2.0, 1.0, -4.0), aspect=w / h)
     f.lights = _small_lights(np.random.default_rng(3), nl, 0.03)

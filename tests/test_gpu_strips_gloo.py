@@ -45,7 +45,7 @@ def _worker(rank, world, port, out_path, with_mesh=False):
         r = StripRenderer(plan, W, device=dev)
         mesh = None
         if with_mesh:
-            verts, tris = synth.make_sphere_mesh()
+            verts, tris = synth.reference_light_volume()
             mesh = (torch.from_numpy(verts).to(dev), torch.from_numpy(tris.astype(np.int32)).to(dev))
         r.render(P.DeviceFrame.upload(f.rows(plan.row0, plan.row0 + plan.rows), dev), mesh)
         parts = r.gather(0)
@@ -84,7 +84,7 @@ def test_hip_strips_with_light_volume_coverage(gpu, oracle, tmp_path):
     oracle's image under the whole-frame masks (8-bit, within 1 LSB)."""
     import torch.multiprocessing as mp
     f = _local_light_frame()
-    verts, tris = synth.make_sphere_mesh()
+    verts, tris = synth.reference_light_volume()
     masks = oracle.light_coverage(f.scene, f.lights, verts, tris, W, H)
     color, thr = oracle.shade(f, coverage=masks)
     b2 = oracle.bloom_blur(oracle.bloom_blur(thr, True, oracle.WRAP_REPEAT), False, oracle.WRAP_CLAMP)

@@ -38,16 +38,17 @@ class OracleIblBackend:
         flat_out[rows[0]:rows[1]] = flat_whole[rows[0]:rows[1]]
 
     def sampling_copy(self, env):
-        return env, 0
+        return env, 0, env.shape[1]
 
-    def irradiance(self, env, out, rows, env_layout=0, order=0, linear=None):
+    def irradiance(self, sampled, out, rows, order=-1, linear=None):
         from tests import oracle
         order = 3 if order == -1 else order   # IRRADIANCE_FASTEST is the by-region order with row sums
-        self._rows(out, oracle.irradiance(self._bits(env), out.shape[1], order), rows)
+        self._rows(out, oracle.irradiance(self._bits(sampled[0]), out.shape[1], order), rows)
 
-    def prefilter(self, env, out, roughness, rows, env_layout=0):
+    def prefilter_mips(self, sampled, cubes, rows):
         from tests import oracle
-        self._rows(out, oracle.prefilter(self._bits(env), out.shape[1], roughness), rows)
+        for m, (out, r) in enumerate(zip(cubes, rows)):
+            self._rows(out, oracle.prefilter(self._bits(sampled[0]), out.shape[1], m / max(len(cubes) - 1, 1)), r)
 
     def brdf_lut(self, out, rows):
         from tests import oracle
@@ -76,7 +77,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_ibl_equals_the_single_device_images(world, tmp_path, oracle):
     src = _source().numpy().view(np.uint16)
     env = oracle.equirect_to_cube(src, CFG.env_res)

@@ -91,7 +91,7 @@ def _worker(rank, world, port, out_path, with_mesh=False):
         f = _local_light_frame() if with_mesh else _frame()
         plan = StripPlan.make(rank, world, H)
         r = StripRenderer(plan, W, backend=OracleBackend())
-        r.render(f.rows(plan.row0, plan.row0 + plan.rows), synth.make_sphere_mesh() if with_mesh else None)
+        r.render(f.rows(plan.row0, plan.row0 + plan.rows), synth.reference_light_volume() if with_mesh else None)
         parts = r.gather(0)
         if rank == 0:
             np.save(out_path, torch.cat(parts, 0).numpy())
@@ -107,7 +107,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_strips_reassemble_to_the_single_device_image(world, tmp_path, oracle):
     want = oracle.frame_chain(_frame())["ldr"]
     out_path = str(tmp_path / "ldr.npy")
@@ -121,7 +121,7 @@ def test_strips_with_light_volume_coverage(tmp_path, oracle):
     """Each rank rasterises the light volumes for its own rows (placed in the frame by row0): the
     assembled image is the single-device image under the whole-frame masks."""
     f = _local_light_frame()
-    verts, tris = synth.make_sphere_mesh()
+    verts, tris = synth.reference_light_volume()
     masks = oracle.light_coverage(f.scene, f.lights, verts, tris, W, H)
     frac = oracle.coverage_to_image(masks, W, H).mean()
     assert 0.02 < frac < 0.95, frac

@@ -65,8 +65,12 @@ def frame_vectors(spv_dir, name, rng, W, H, cube_res, dir_res, seed, light_pos, 
     res_comp = {(1, 0): gb["albedo"], (1, 1): gb["normal"], (1, 2): gb["arm"], (1, 3): gb["position"],
                 (2, 0): TexCube(h2f(f.irradiance), "linear"), (2, 1): Tex2D(h2f(f.brdf_lut), "linear", "repeat"),
                 (2, 2): TexCube(h2f(f.prefilter), "linear"), (3, 0): Tex2D(f.dir_shadow[..., None], "nearest", "border", 1.0)}
+    light_maxnum = Shader(os.path.join(spv_dir, "light.frag.spv"), nan_max="maxnum")
     color = np.zeros((H, W, 3), np.float32)
     thr = np.zeros((H, W, 3), np.float32)
+    # light.frag on cleared texels (normal 0: normalize() yields NaN, and max() of a NaN is undefined in GLSL): what
+    # the shader's two outputs are when max() propagates the NaN and when it returns the other operand
+    cleared_px, cleared_propagate, cleared_maxnum = [], [], []
     comp_raw = np.zeros((H, W, 3), np.float32)
     light_raw = np.zeros((NL, H, W, 3), np.float32)
     killed = np.zeros((H, W), bool)
@@ -85,7 +89,13 @@ def frame_vectors(spv_dir, name, rng, W, H, cube_res, dir_res, seed, light_pos, 
                          (2, 0): TexCube(f.cube_shadow[li][..., None], "nearest")}
                 nrm = h2f(f.normal)[y, x, :3]
                 if not nrm.any():
-                    continue  # cleared texel: the shader's result is implementation-dependent (NaN normal)
+                    # cleared texel: the result depends on the implementation's max(); recorded, and left out of the blend
+                    inp = {0: f.lights["color"][li], 1: f.lights["position"][li], 2: scene["camera_position"], "frag_coord": (x + 0.5, y + 0.5, 0.5, 1.0)}
+                    a, b = light.run(inp, res_l)["out"], light_maxnum.run(inp, res_l)["out"]
+                    cleared_px.append((li, y, x))
+                    cleared_propagate.append(np.concatenate([a[0][:3], a[1][:3]]))
+                    cleared_maxnum.append(np.concatenate([b[0][:3], b[1][:3]]))
+                    continue
                 rl = light.run({0: f.lights["color"][li], 1: f.lights["position"][li], 2: scene["camera_position"],
                                 "frag_coord": (x + 0.5, y + 0.5, 0.5, 1.0)}, res_l)
                 light_raw[li, y, x] = rl["out"][0][:3]
@@ -96,7 +106,10 @@ def frame_vectors(spv_dir, name, rng, W, H, cube_res, dir_res, seed, light_pos, 
     np.savez_compressed(os.path.join(OUT, name),
                         albedo=f.albedo, normal=f.normal, arm=f.arm, position=f.position, scene=scene, lights=f.lights,
                         dir_shadow=f.dir_shadow, cube_shadow=f.cube_shadow, irradiance=f.irradiance, prefilter=f.prefilter,
-                        brdf_lut=f.brdf_lut, color=color, threshold=thr, killed=killed, near_threshold=near_threshold)
+                        brdf_lut=f.brdf_lut, color=color, threshold=thr, killed=killed, near_threshold=near_threshold,
+                        cleared_px=np.array(cleared_px, dtype=np.int32).reshape(-1, 3),
+                        cleared_light_out_max_propagates_nan=np.array(cleared_propagate, dtype=np.float32).reshape(-1, 6),
+                        cleared_light_out_max_is_maxnum=np.array(cleared_maxnum, dtype=np.float32).reshape(-1, 6))
     print(name, time.time() - t0, "s; ops", comp.ops + light.ops, "killed", killed.sum(), "near thr", near_threshold.sum())
 
 
@@ -189,6 +202,97 @@ def main(spv_dir):
                         irradiance_texels=np.array(irr_texels), irradiance=irr_out,
                         prefilter_cases=np.array(pre_cases, dtype=np.float32), prefilter=pre_out, brdf_lut=brdf_out)
     print("done", time.time() - t0, "s")
+
+
+def ibl_vectors_large(spv_dir):
+    """The four IBL shaders on an environment with an interior: 1024^2 faces (bilinear footprints away from every seam,
+    2 x 2 regions of 512^2 texels and 3 x 3 regions of the footprint-tile order per face).  The environment itself is
+    too large for a fixture: it is synth.make_env_cube(default_rng(505), 1024, sun_peak=6.0), and the fixture holds its
+    SHA-256 so that a test can tell a changed generator from a wrong kernel."""
+    import hashlib
+    t0 = time.time()
+    env_n = 1024
+    env_bits = synth.make_env_cube(np.random.default_rng(505), env_n, sun_peak=6.0)
+    digest = hashlib.sha256(np.ascontiguousarray(env_bits).tobytes()).hexdigest()
+    env = TexCube(h2f(env_bits), "linear")
+    irr = Shader(os.path.join(spv_dir, "irradiance.frag.spv"))
+    irr_n = 8   # texels of an 8^2 irradiance cube: face centres, edges, corners
+    irr_texels = [(0, 3, 3), (0, 0, 0), (1, 7, 4), (2, 0, 7), (2, 4, 4), (3, 3, 0), (4, 7, 7), (5, 2, 5), (4, 0, 3), (1, 4, 0), (3, 7, 7), (5, 0, 0)]
+    irr_out = np.zeros((len(irr_texels), 4), np.float32)
+    for k, (fc, i, j) in enumerate(irr_texels):
+        irr_out[k] = irr.run({0: face_dir(fc, i, j, irr_n)}, {(1, 0): env})["out"][0]
+    print("  irradiance", time.time() - t0, "s")
+    pre = Shader(os.path.join(spv_dir, "prefilter.frag.spv"))
+    pre_n = 16
+    pre_cases = [(0.0, 0, 7, 8), (0.0, 3, 0, 0), (0.25, 1, 0, 0), (0.25, 4, 8, 8), (0.5, 2, 15, 3), (0.5, 5, 8, 0), (0.75, 3, 4, 12), (0.75, 0, 15, 15),
+                 (1.0, 0, 0, 15), (1.0, 4, 7, 7)]
+    pre_out = np.zeros((len(pre_cases), 4), np.float32)
+    for k, (r, fc, i, j) in enumerate(pre_cases):
+        pre_out[k] = pre.run({0: face_dir(fc, i, j, pre_n)}, {(1, 0): env, "push": [F(r)]})["out"][0]
+    print("  prefilter", time.time() - t0, "s")
+    brdf = Shader(os.path.join(spv_dir, "brdf.frag.spv"))
+    bn = 32
+    brdf_out = np.zeros((bn, bn, 2), np.float32)
+    for j in range(bn):
+        for i in range(bn):
+            uv = np.array([(F(i) + F(0.5)) / F(bn), (F(j) + F(0.5)) / F(bn)], dtype=np.float32)
+            brdf_out[j, i] = brdf.run({0: uv}, {})["out"][0]
+    print("  brdf", time.time() - t0, "s")
+    equi = Shader(os.path.join(spv_dir, "equirectangular_to_cubemap.frag.spv"))
+    eq_src = synth.make_equirect(np.random.default_rng(606), 128, 64, hdr=True)
+    tsrc = Tex2D(h2f(eq_src), "linear", "repeat")
+    en = 16
+    eq_out = np.zeros((6, en, en, 4), np.float32)
+    for fc in range(6):
+        for j in range(en):
+            for i in range(en):
+                eq_out[fc, j, i] = equi.run({0: face_dir(fc, i, j, en)}, {(1, 0): tsrc})["out"][0]
+    np.savez_compressed(os.path.join(OUT, "ibl_1024.npz"), env_n=env_n, env_seed=505, env_sun_peak=6.0, env_sha256=digest,
+                        irradiance_n=irr_n, irradiance_texels=np.array(irr_texels), irradiance=irr_out,
+                        prefilter_n=pre_n, prefilter_cases=np.array(pre_cases, dtype=np.float32), prefilter=pre_out, brdf_lut=brdf_out,
+                        equirect_src=eq_src, equirect_cube=eq_out)
+    print("ibl_1024 vectors written", time.time() - t0, "s")
+
+
+def light_volume_mesh(glb_path):
+    """The reference's light-volume mesh (assets/models/sphere/sphere.glb, loaded at VulkanRenderer.cs:269 and drawn
+    once per light at :479-498) as arrays: positions and triangle indices of its one primitive.  A .glb is a JSON
+    chunk that describes buffer views into a binary chunk; nothing of the file but these two arrays is kept."""
+    import json
+    import struct
+    raw = open(glb_path, "rb").read()
+    magic, version, length = struct.unpack_from("<4sII", raw, 0)
+    assert magic == b"glTF" and version == 2 and length == len(raw)
+    off, chunks = 12, {}
+    while off < len(raw):
+        clen, ctype = struct.unpack_from("<I4s", raw, off)
+        chunks[ctype] = raw[off + 8:off + 8 + clen]
+        off += 8 + clen
+    doc, blob = json.loads(chunks[b"JSON"]), chunks[b"BIN\x00"]
+    comp = {5120: np.int8, 5121: np.uint8, 5122: np.int16, 5123: np.uint16, 5125: np.uint32, 5126: np.float32}
+    width = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4}
+
+    def accessor(idx):
+        acc = doc["accessors"][idx]
+        view = doc["bufferViews"][acc["bufferView"]]
+        dt, w = np.dtype(comp[acc["componentType"]]), width[acc["type"]]
+        start = view.get("byteOffset", 0) + acc.get("byteOffset", 0)
+        stride = view.get("byteStride", 0) or dt.itemsize * w
+        rows = np.lib.stride_tricks.as_strided(np.frombuffer(blob, dtype=np.uint8, offset=start), shape=(acc["count"], dt.itemsize * w), strides=(stride, 1))
+        return np.ascontiguousarray(rows).view(dt).reshape(acc["count"], w)
+
+    assert len(doc["meshes"]) == 1 and len(doc["meshes"][0]["primitives"]) == 1
+    prim = doc["meshes"][0]["primitives"][0]
+    assert prim.get("mode", 4) == 4   # triangles
+    pos = accessor(prim["attributes"]["POSITION"]).astype(np.float32)
+    tri = accessor(prim["indices"]).astype(np.uint32).reshape(-1, 3)
+    # the node transforms of the file, if any, are part of what Assimp hands the reference
+    node = next(n for n in doc["nodes"] if "mesh" in n)
+    transform = {k: node[k] for k in ("matrix", "translation", "rotation", "scale") if k in node}
+    np.savez_compressed(os.path.join(OUT, "light_volume.npz"), positions=pos, triangles=tri,
+                        node_transform=json.dumps(transform))
+    radius = np.linalg.norm(pos.astype(np.float64), axis=1)
+    print("light volume:", len(pos), "vertices,", len(tri), "triangles, radius", radius.min(), "..", radius.max(), "node transform", transform)
 
 
 def light_vert_vectors(spv_dir):
@@ -370,6 +474,15 @@ if __name__ == "__main__":
     spv = args[0] if args else "/root/reference/compiled_shaders"
     if "--only-large-frame" in sys.argv:
         frame_vectors_large(spv)
+    elif "--only-ibl-large" in sys.argv:
+        ibl_vectors_large(spv)
+    elif "--only-light-volume" in sys.argv:
+        light_volume_mesh(os.path.join(os.path.dirname(spv.rstrip("/")), "assets", "models", "sphere", "sphere.glb"))
+    elif "--only-frames" in sys.argv:
+        rng = np.random.default_rng(99)
+        frame_vectors(spv, "frame_composition_lights.npz", rng, 16, 12, 8, 16, 1234,
+                      [(0.8, 1.7, -0.6), (-1.4, 2.3, 1.1)], [(30.0, 25.0, 20.0), (9.0, 21.0, 24.0)], (slice(4, 8), slice(8, 12)), time.time())
+        frame_vectors_large(spv)
     elif "--only-light-vert" in sys.argv:
         light_vert_vectors(spv)
     elif "--only-gpass" in sys.argv:
@@ -381,6 +494,8 @@ if __name__ == "__main__":
     else:
         main(spv)
         frame_vectors_large(spv)
+        ibl_vectors_large(spv)
+        light_volume_mesh(os.path.join(os.path.dirname(spv.rstrip("/")), "assets", "models", "sphere", "sphere.glb"))
         light_vert_vectors(spv)
         gpass_vectors(spv)
         skybox_vectors(spv)

@@ -268,9 +268,12 @@ class Shader:
     resources: {(set, binding): Tex2D | TexCube}, plus "push" = list of push-constant member values
     """
 
-    def __init__(self, path):
+    def __init__(self, path, nan_max="propagate"):
+        """nan_max: what max / min / clamp return when an operand is NaN, which GLSL leaves undefined: "propagate" (NaN,
+        numpy's maximum) or "maxnum" (the other operand, IEEE 754-2008 maxNum, what v_max_f32 and most GPUs do)."""
         self.m = Module(path)
         self.ops = 0
+        self._max, self._min = (np.fmax, np.fmin) if nan_max == "maxnum" else (np.maximum, np.minimum)
 
     # ---- helpers ----
     def _default(self, ty):
@@ -502,9 +505,9 @@ class Shader:
             if inst == 31:
                 return _f(np.sqrt(x[0]))
             if inst == 40:
-                return _f(np.maximum(x[0], x[1]))
+                return _f(self._max(x[0], x[1]))
             if inst == 43:
-                return _f(np.minimum(np.maximum(x[0], x[1]), x[2]))
+                return _f(self._min(self._max(x[0], x[1]), x[2]))
             if inst == 46:   # mix(x, y, a) = x*(1-a) + y*a
                 return _f(_f(x[0] * _f(F(1) - x[2])) + _f(x[1] * x[2]))
             if inst == 66:

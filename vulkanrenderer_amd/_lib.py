@@ -128,6 +128,14 @@ class BloomChainArgs(C.Structure):
                 ("wrap_v", C.c_int32), ("clamp_lo_v", C.c_int32), ("clamp_hi_v", C.c_int32), ("flags", C.c_int32)]
 
 
+PREFILTER_MAX_MIPS = 8
+
+
+class PrefilterMipsArgs(C.Structure):
+    _fields_ = [("env", C.c_void_p), ("env_res", C.c_int32), ("env_layout", C.c_int32), ("base_res", C.c_int32), ("mips", C.c_int32),
+                ("out", C.c_void_p * PREFILTER_MAX_MIPS), ("row_begin", C.c_int32 * PREFILTER_MAX_MIPS), ("row_end", C.c_int32 * PREFILTER_MAX_MIPS)]
+
+
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "device", "width", "height", "max_lights", "dir_shadow_res", "point_shadow_res", "env_res",
@@ -169,6 +177,7 @@ PROTOTYPES = {
     "vkr_ibl_irradiance_by_region_rows": [_vp, _i32, _vp, _i32, _i32, _i32, _vp, C.c_int64, _vp],
     "vkr_ibl_irradiance_by_region_rows_workspace_bytes": [_i32, _i32, _i32, _i32],
     "vkr_ibl_prefilter": [_vp, _i32, _i32, _vp, _i32, _f, _i32, _i32, _vp],
+    "vkr_ibl_prefilter_mips": [_vp, _vp],
     "vkr_tile_rgba16f_faces": [_vp, _vp, _i32, _i32, _vp],
     "vkr_measure_peaks": [C.POINTER(C.c_float), C.POINTER(C.c_float)],
     "vkr_ibl_brdf_lut": [_vp, _i32, _i32, _i32, _vp],

@@ -5,6 +5,8 @@
 #include <stdarg.h>
 #include <string.h>
 #include <new>
+#include <map>
+#include <utility>
 #include <vector>
 #include "vkr_host.h"
 
@@ -48,11 +50,14 @@ struct vkr_ctx {
     void *env = nullptr, *irradiance = nullptr, *brdf_lut = nullptr;
     std::vector<void *> prefilter;  // one image per mip
     bool have_env = false, have_irr = false, have_pref = false, have_lut = false;
-    void *env_tiled = nullptr;      // the environment cube as 4x4-texel tiles (what the IBL passes sample)
+    void *env_tiled = nullptr;      // the environment cube as 4x4-texel tiles (what the skybox draw samples)
+    void *env_foot = nullptr;       // the environment cube in footprint tiles (what the IBL passes sample), made on first use
+    bool env_foot_valid = false;    // env_foot holds the current environment
     float *cube_staging = nullptr;  // one linear depth cube on its way into the tiled storage
     float *mesh_verts = nullptr;    // light-volume mesh (vkr_set_light_volume_mesh)
     uint32_t *mesh_indices = nullptr;
     int mesh_n_verts = 0, mesh_n_tris = 0;
+    bool mesh_closed = false;       // every directed edge of the volume mesh has exactly one opposite twin (by position)
     struct Mesh { float *positions; uint32_t *indices; int n_verts, n_tris; float *texcoords, *normals, *tangents; };
     struct Material { VkrTexture albedo, normal, arm; };
     std::vector<Mesh> meshes;            // vkr_create_mesh
@@ -161,7 +166,7 @@ static void destroy(vkr_ctx *c)
         if (f.cube_shadow) (void)hipFree(f.cube_shadow);
         if (f.lights) (void)hipFree(f.lights);
     }
-    void *ibl[] = {c->env, c->env_tiled, c->irradiance, c->brdf_lut, c->cube_staging, c->mesh_verts, c->mesh_indices};
+    void *ibl[] = {c->env, c->env_tiled, c->env_foot, c->irradiance, c->brdf_lut, c->cube_staging, c->mesh_verts, c->mesh_indices};
     for (auto &m : c->meshes) {
         (void)hipFree(m.positions); (void)hipFree(m.indices);
         if (m.texcoords) (void)hipFree(m.texcoords);
@@ -220,7 +225,7 @@ static int32_t fill_shade_args(vkr_ctx *c, Frame &f, VkrShadeArgs &a)
     a.brdf_lut = c->brdf_lut; a.lut_res = c->cfg.brdf_lut_res;
     a.out_color = f.color; a.out_threshold = f.threshold;
     a.coverage_masks = f.coverage == VKR_COVERAGE_MESH ? f.coverage_buf : nullptr;
-    a.coverage_flags = f.coverage == VKR_COVERAGE_MESH ? coverage_flags(c, f) : nullptr;
+    a.coverage_flags = f.coverage == VKR_COVERAGE_MESH && c->mesh_closed ? coverage_flags(c, f) : nullptr;
     return VKR_OK;
 }
 
@@ -310,7 +315,8 @@ static int32_t run_coverage(vkr_ctx *c, Frame &f)
     a.verts = c->mesh_verts; a.n_verts = c->mesh_n_verts;
     a.indices = c->mesh_indices; a.n_tris = c->mesh_n_tris;
     a.masks = f.coverage_buf;
-    a.light_flags = coverage_flags(c, f);
+    // "covers every pixel" is concluded from back faces alone, which holds for a closed mesh only
+    a.light_flags = c->mesh_closed ? coverage_flags(c, f) : nullptr;
     return vkr_light_coverage(&a, c->stream);
 }
 
@@ -337,6 +343,36 @@ static VkrBloomArgs bloom_args(vkr_ctx *c, Frame &f, int horizontal)
     b.wrap = horizontal ? VKR_WRAP_REPEAT : VKR_WRAP_CLAMP;
     b.clamp_lo = 0; b.clamp_hi = c->cfg.height - 1;
     return b;
+}
+
+// Whether a triangle mesh is closed and consistently wound: every directed edge between two different positions occurs
+// once, and so does its opposite.  Vertices are matched by position (bit for bit), not by index: meshes that carry
+// texture coordinates repeat the positions along a seam (the reference's sphere.glb has 559 vertices at 482 positions).
+static bool mesh_is_closed(const float *verts, const uint32_t *indices, int n_tris)
+{
+    struct Key { uint32_t x, y, z; bool operator<(const Key &o) const { return x != o.x ? x < o.x : (y != o.y ? y < o.y : z < o.z); } };
+    auto key = [&](uint32_t v) {
+        Key k;
+        float p[3] = {verts[3 * v] + 0.0f, verts[3 * v + 1] + 0.0f, verts[3 * v + 2] + 0.0f};  // -0 and +0 are one position
+        memcpy(&k, p, 12);
+        return k;
+    };
+    std::map<Key, uint32_t> ids;
+    std::map<std::pair<uint32_t, uint32_t>, int> edges;
+    for (int t = 0; t < n_tris; t++) {
+        uint32_t id[3];
+        for (int k = 0; k < 3; k++) id[k] = ids.emplace(key(indices[3 * t + k]), (uint32_t)ids.size()).first->second;
+        for (int k = 0; k < 3; k++) {
+            const uint32_t a = id[k], b = id[(k + 1) % 3];
+            if (a != b) edges[{a, b}]++;
+        }
+    }
+    for (const auto &e : edges) {
+        if (e.second != 1) return false;
+        auto twin = edges.find({e.first.second, e.first.first});
+        if (twin == edges.end() || twin->second != 1) return false;
+    }
+    return !edges.empty();
 }
 
 }  // namespace vkr
@@ -382,6 +418,7 @@ extern "C" int32_t vkr_create(const VkrConfig *config, vkr_ctx **out)
     VKR_REQUIRE(cfg.max_lights > 0 && cfg.frames_in_flight > 0 && cfg.frames_in_flight <= 8, "vkr_create: bad max_lights / frames_in_flight");
     VKR_REQUIRE(cfg.dir_shadow_res > 0 && cfg.dir_shadow_res <= 32768 && cfg.point_shadow_res > 0 && cfg.point_shadow_res <= 8192, "vkr_create: bad shadow map size");
     VKR_REQUIRE(cfg.env_res > 0 && cfg.irradiance_res > 0 && cfg.prefilter_res > 0 && cfg.brdf_lut_res > 0, "vkr_create: bad IBL size");
+    VKR_REQUIRE(cfg.prefilter_mips <= VKR_PREFILTER_MAX_MIPS, "vkr_create: %d prefilter mips; at most %d are supported", cfg.prefilter_mips, VKR_PREFILTER_MAX_MIPS);
     VKR_REQUIRE(cfg.prefilter_mips > 0 && (cfg.prefilter_res >> (cfg.prefilter_mips - 1)) > 0, "vkr_create: %d mips do not fit a %d^2 prefilter cube", cfg.prefilter_mips, cfg.prefilter_res);
 
     int n = 0;
@@ -510,6 +547,7 @@ extern "C" int32_t vkr_set_light_volume_mesh(vkr_ctx *c, const float *verts, int
     VKR_REQUIRE(n_verts <= 1024, "vkr_set_light_volume_mesh: %d vertices; at most 1024 are supported", n_verts);
     for (int64_t i = 0; i < (int64_t)n_tris * 3; i++)
         VKR_REQUIRE(indices[i] < (uint32_t)n_verts, "vkr_set_light_volume_mesh: index %u at %lld is outside the %d vertices", indices[i], (long long)i, n_verts);
+    const bool closed = mesh_is_closed(verts, indices, n_tris);
     // the new mesh replaces the old one only once it is complete on the device
     float *new_verts = nullptr;
     uint32_t *new_indices = nullptr;
@@ -523,6 +561,7 @@ extern "C" int32_t vkr_set_light_volume_mesh(vkr_ctx *c, const float *verts, int
     if (c->mesh_indices) (void)hipFree(c->mesh_indices);
     c->mesh_verts = new_verts; c->mesh_indices = new_indices;
     c->mesh_n_verts = n_verts; c->mesh_n_tris = n_tris;
+    c->mesh_closed = closed;
     return VKR_OK;
 }
 
@@ -671,6 +710,7 @@ extern "C" int32_t vkr_create_skybox_cubemap(vkr_ctx *c, const void *equirect, i
     if (rc != VKR_OK) return rc;
     if (e != hipSuccess) return fail(VKR_ERR_HIP, "vkr_create_skybox_cubemap: %s", hipGetErrorString(e));
     c->have_env = true;
+    c->env_foot_valid = false;
     return VKR_OK;
 }
 
@@ -684,6 +724,21 @@ extern "C" int32_t vkr_upload_env_cube(vkr_ctx *c, const void *cube)
         if (rc == VKR_OK) VKR_HIP_CHECK(hipStreamSynchronize(c->stream));
     }
     if (rc == VKR_OK) c->have_env = true;
+    c->env_foot_valid = false;
+    return rc;
+}
+
+// The environment in footprint tiles (every 2x2 footprint of a LINEAR lookup in one cache line): the copy the
+// irradiance pass in its default order and the prefilter passes read.  Made when first asked for after the
+// environment changed; enqueued on the context's stream.
+static int32_t ensure_env_footprints(vkr_ctx *c)
+{
+    if (c->env_foot_valid) return VKR_OK;
+    const int64_t bytes = vkr_env_footprint_tiles_bytes(c->cfg.env_res);
+    if (bytes < 0) return VKR_ERR_INVALID;
+    if (!c->env_foot) VKR_HIP_CHECK(hipMalloc(&c->env_foot, (size_t)bytes));
+    const int32_t rc = vkr_tile_rgba16f_footprints(c->env, c->env_foot, c->cfg.env_res, c->stream);
+    if (rc == VKR_OK) c->env_foot_valid = true;
     return rc;
 }
 
@@ -696,20 +751,18 @@ extern "C" int32_t vkr_create_irradiance_cubemap(vkr_ctx *c, int32_t order)
     const int32_t n = c->cfg.irradiance_res;
     if (order == VKR_IRRADIANCE_FASTEST) order = VKR_IRRADIANCE_BY_REGION_ROWS;
     if (order == VKR_IRRADIANCE_BY_REGION || order == VKR_IRRADIANCE_BY_REGION_ROWS) {
-        // a one-off step: the workspace (and, for the rows order, the environment in footprint tiles) lives for this call only
+        // a one-off step: the workspace lives for this call only
         const bool rows = order == VKR_IRRADIANCE_BY_REGION_ROWS;
         const int64_t bytes = rows ? vkr_ibl_irradiance_by_region_rows_workspace_bytes(c->cfg.env_res, n, 0, 6 * n)
                                    : vkr_ibl_irradiance_by_region_workspace_bytes(c->cfg.env_res, n, 0, 6 * n);
-        const int64_t tile_bytes = rows ? vkr_env_footprint_tiles_bytes(c->cfg.env_res) : 0;
-        if (bytes < 0 || tile_bytes < 0) return VKR_ERR_INVALID;
-        char *ws = nullptr;  // [workspace][tiles], the tiles 256-byte aligned
-        const int64_t tiles_at = (bytes + 255) & ~(int64_t)255;
-        VKR_HIP_CHECK(hipMalloc((void **)&ws, (size_t)(tiles_at + tile_bytes)));
-        int32_t rc = VKR_OK;
-        if (rows) {
-            rc = vkr_tile_rgba16f_footprints(c->env, ws + tiles_at, c->cfg.env_res, c->stream);
-            if (rc == VKR_OK) rc = vkr_ibl_irradiance_by_region_rows(ws + tiles_at, c->cfg.env_res, c->irradiance, n, 0, 6 * n, ws, bytes, c->stream);
-        } else
+        if (bytes < 0) return VKR_ERR_INVALID;
+        int32_t rc = rows ? ensure_env_footprints(c) : VKR_OK;
+        if (rc != VKR_OK) return rc;
+        char *ws = nullptr;
+        VKR_HIP_CHECK(hipMalloc((void **)&ws, (size_t)bytes));
+        if (rows)
+            rc = vkr_ibl_irradiance_by_region_rows(c->env_foot, c->cfg.env_res, c->irradiance, n, 0, 6 * n, ws, bytes, c->stream);
+        else
             rc = vkr_ibl_irradiance_by_region(env, c->cfg.env_res, layout, c->irradiance, n, 0, 6 * n, ws, bytes, c->stream);
         uint32_t uncovered = 0;
         hipError_t e = hipStreamSynchronize(c->stream);
@@ -732,15 +785,14 @@ extern "C" int32_t vkr_create_prefiltered_cubemap(vkr_ctx *c)
 {
     VKR_CTX(c);
     if (!c->have_env) return fail(VKR_ERR_ORDER, "vkr_create_prefiltered_cubemap: no environment cube yet");
-    const void *env = c->env_tiled ? c->env_tiled : c->env;
-    const int32_t layout = c->env_tiled ? VKR_ENV_LAYOUT_TILED_4X4 : VKR_ENV_LAYOUT_LINEAR;
-    for (int m = 0; m < c->cfg.prefilter_mips; m++) {
-        // VulkanRenderer.cs:874: roughness = mip / (mips - 1)
-        float rough = c->cfg.prefilter_mips > 1 ? (float)m / (float)(c->cfg.prefilter_mips - 1) : 0.0f;
-        int n = c->cfg.prefilter_res >> m;
-        int32_t rc = vkr_ibl_prefilter(env, c->cfg.env_res, layout, c->prefilter[m], n, rough, 0, 6 * n, c->stream);
-        if (rc != VKR_OK) return rc;
-    }
+    int32_t rc = ensure_env_footprints(c);
+    if (rc != VKR_OK) return rc;
+    VkrPrefilterMipsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.env = c->env_foot; a.env_res = c->cfg.env_res; a.env_layout = VKR_ENV_LAYOUT_FOOTPRINT_TILES;
+    a.base_res = c->cfg.prefilter_res; a.mips = c->cfg.prefilter_mips;  // roughness of mip m = m / (mips - 1), VulkanRenderer.cs:874
+    for (int m = 0; m < a.mips; m++) { a.out[m] = c->prefilter[m]; a.row_begin[m] = 0; a.row_end[m] = 6 * (c->cfg.prefilter_res >> m); }
+    if ((rc = vkr_ibl_prefilter_mips(&a, c->stream)) != VKR_OK) return rc;
     VKR_HIP_CHECK(hipStreamSynchronize(c->stream));
     c->have_pref = true;
     return VKR_OK;

@@ -654,25 +654,37 @@ VKR_DEV f3 irr_footprint_filter(const irr_footprint &fp, bool corners, u32x4_a8 
 {
     const float al = fp.al, be = fp.be;
     const float w0 = (1.0f - al) * (1.0f - be), w1 = al * (1.0f - be), w2 = (1.0f - al) * be, w3 = al * be;
-    if (!corners) {
-        // the binary16 texels go into the fmas as they are (v_fma_mix_f32 converts on the way in: the same values, twelve
-        // conversions fewer); w0 * t0 as fma(w0, t0, -0), which has the product's bits whatever its sign
-        const float z = -0.0f;
-        return mk3(fma_mix_lo(w3, r1.z, fma_mix_lo(w2, r1.x, fma_mix_lo(w1, r0.z, fma_mix_lo(w0, r0.x, z)))),
-                   fma_mix_hi(w3, r1.z, fma_mix_hi(w2, r1.x, fma_mix_hi(w1, r0.z, fma_mix_hi(w0, r0.x, z)))),
-                   fma_mix_lo(w3, r1.w, fma_mix_lo(w2, r1.y, fma_mix_lo(w1, r0.w, fma_mix_lo(w0, r0.y, z)))));
-    }
-    rgba tx[4] = {unpack4(make_uint2(r0.x, r0.y)), unpack4(make_uint2(r0.z, r0.w)), unpack4(make_uint2(r1.x, r1.y)), unpack4(make_uint2(r1.z, r1.w))};
-    if (__builtin_expect(fp.missing >= 0, 0)) {  // the texel beyond both edges is the mean of the other three
+    if (__builtin_expect(corners && fp.missing >= 0, 0)) {  // the texel beyond both edges is the mean of the other three
+        rgba tx[4] = {unpack4(make_uint2(r0.x, r0.y)), unpack4(make_uint2(r0.z, r0.w)), unpack4(make_uint2(r1.x, r1.y)), unpack4(make_uint2(r1.z, r1.w))};
         float sr = 0.0f, sg = 0.0f, sb = 0.0f;
 #pragma unroll
         for (int q = 0; q < 4; q++) if (q != fp.missing) { sr += tx[q].r; sg += tx[q].g; sb += tx[q].b; }
 #pragma unroll
         for (int q = 0; q < 4; q++) if (q == fp.missing) { tx[q].r = sr * (1.0f / 3.0f); tx[q].g = sg * (1.0f / 3.0f); tx[q].b = sb * (1.0f / 3.0f); }
+        return mk3(fma_(w3, tx[3].r, fma_(w2, tx[2].r, fma_(w1, tx[1].r, w0 * tx[0].r))),
+                   fma_(w3, tx[3].g, fma_(w2, tx[2].g, fma_(w1, tx[1].g, w0 * tx[0].g))),
+                   fma_(w3, tx[3].b, fma_(w2, tx[2].b, fma_(w1, tx[1].b, w0 * tx[0].b))));
     }
-    return mk3(fma_(w3, tx[3].r, fma_(w2, tx[2].r, fma_(w1, tx[1].r, w0 * tx[0].r))),
-               fma_(w3, tx[3].g, fma_(w2, tx[2].g, fma_(w1, tx[1].g, w0 * tx[0].g))),
-               fma_(w3, tx[3].b, fma_(w2, tx[2].b, fma_(w1, tx[1].b, w0 * tx[0].b))));
+    // the binary16 texels go into the fmas as they are (v_fma_mix_f32 converts on the way in: the same values, twelve
+    // conversions fewer); w0 * t0 as fma(w0, t0, -0), which has the product's bits whatever its sign
+    const float z = -0.0f;
+    return mk3(fma_mix_lo(w3, r1.z, fma_mix_lo(w2, r1.x, fma_mix_lo(w1, r0.z, fma_mix_lo(w0, r0.x, z)))),
+               fma_mix_hi(w3, r1.z, fma_mix_hi(w2, r1.x, fma_mix_hi(w1, r0.z, fma_mix_hi(w0, r0.x, z)))),
+               fma_mix_lo(w3, r1.w, fma_mix_lo(w2, r1.y, fma_mix_lo(w1, r0.w, fma_mix_lo(w0, r0.y, z)))));
+}
+
+// LINEAR, seamless lookup along r in a cube stored in footprint tiles (`tiles`: the whole cube): texcube_rgb_linear
+// with the four texels from one tile.
+VKR_DEV f3 texcube_rgb_linear_footprint_tiles(const char *tiles, int n, unsigned tiles_per_side, f3 r)
+{
+    int face; float s, t;
+    cube_st(r, face, s, t);
+    const float x = s * (float)n - 0.5f, y = t * (float)n - 0.5f;
+    // a non-finite direction (a texel without a tangent frame) has NaN coordinates, which the conversion takes to 0
+    const irr_footprint fp = irr_footprint_at(n, 128u * tiles_per_side - 96u, true, __builtin_fminf(__builtin_fmaxf(x, -1.0f), (float)n), __builtin_fminf(__builtin_fmaxf(y, -1.0f), (float)n));
+    const char *fb = tiles + (size_t)face * tiles_per_side * tiles_per_side * 128u;
+    const u32x4_a8 r0 = *(const u32x4_a8 *)(fb + fp.at), r1 = *(const u32x4_a8 *)(fb + fp.at + 32u);
+    return irr_footprint_filter(fp, true, r0, r1);
 }
 
 // One phi row of a (texel, region) pair: the cells bl .. bh of the row are decided exactly and what lands in the region
@@ -908,18 +920,33 @@ VKR_DEV float2 ggx_theta(int s, float rough)
 // issue (mip 0: the 64 summing lanes cost the instructions, and the other waves the waiting, that eight did: 0.80 ->
 // 0.52 ms); two for the smaller mips, which are bound by cache-line traffic and want the occupancy, and so that the
 // small ones fill the chip.
-template <bool TILED, int PREFILTER_TEXELS>
-__global__ __launch_bounds__(256) void prefilter_texel_kernel(const void *env, int env_n, uint2 *out, int n, float rough, int row_begin, int n_texels, int per_xcd)
+// One launch may hold several mips (the small ones together fill the chip where each alone would not): per mip its
+// image, face size, roughness, the rows it computes and the number of texel groups each XCD takes of it.
+static constexpr int PREFILTER_MAX_MIPS = 8;
+struct PrefilterMips {
+    uint2 *out[PREFILTER_MAX_MIPS]; int n[PREFILTER_MAX_MIPS]; float rough[PREFILTER_MAX_MIPS];
+    int row_begin[PREFILTER_MAX_MIPS], n_texels[PREFILTER_MAX_MIPS], per_xcd[PREFILTER_MAX_MIPS];
+    int count;
+};
+template <int LAYOUT, int PREFILTER_TEXELS>
+__global__ __launch_bounds__(256) void prefilter_texel_kernel(const void *env, int env_n, const PrefilterMips mips)
 {
     constexpr int PREFILTER_PASS = 2 * SAMPLE_COUNT / PREFILTER_TEXELS;  // 32 KB of terms either way
     __shared__ __align__(16) float term[PREFILTER_TEXELS][4][PREFILTER_PASS];  // [0..2] environment colour, [3] N.L
     __shared__ __align__(16) float ones[16];
     __shared__ float result[PREFILTER_TEXELS][4];
     const int tid = threadIdx.x;
-    // Workgroups go to the 8 XCDs round-robin by id.  XCD x takes the groups [x * per_xcd, (x + 1) * per_xcd) in row-major
-    // order, so the workgroups resident on an XCD at any time are neighbours on the cube, their lobes overlap, and the
-    // XCD's L2 serves most of their lookups.
-    const int first = PREFILTER_TEXELS * ((int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3));
+    const unsigned tiles_per_side = (unsigned)env_n / 3u + 1u;  // of the footprint-tile layout
+    // Workgroups go to the 8 XCDs round-robin by id.  Of every mip XCD x takes the groups [x * per_xcd, (x + 1) * per_xcd)
+    // in row-major order, so the workgroups resident on an XCD at any time are neighbours on the cube, their lobes
+    // overlap, and the XCD's L2 serves most of their lookups; an XCD works through its share of the first mip of the
+    // launch, then of the next (the largest first).
+    int mip = 0, k = (int)(blockIdx.x >> 3);
+    while (mip + 1 < mips.count && k >= mips.per_xcd[mip]) { k -= mips.per_xcd[mip]; mip++; }
+    uint2 *const out = mips.out[mip];
+    const int n = mips.n[mip], row_begin = mips.row_begin[mip], n_texels = mips.n_texels[mip];
+    const float rough = mips.rough[mip];
+    const int first = PREFILTER_TEXELS * ((int)(blockIdx.x & 7u) * mips.per_xcd[mip] + k);
     if (first >= n_texels) return;
     if (tid < 16) ones[tid] = 1.0f;
     __shared__ float frame[PREFILTER_TEXELS][12];  // N, tangent, bitangent of each texel
@@ -965,7 +992,9 @@ __global__ __launch_bounds__(256) void prefilter_texel_kernel(const void *env, i
                 const f3 L = normalize3_fast(mk3(fma_(vh2, H.x, -N.x), fma_(vh2, H.y, -N.y), fma_(vh2, H.z, -N.z)));
                 const float NdotL = max0(dot3(N, L));
                 f3 c = mk3(0.0f, 0.0f, 0.0f);
-                if (NdotL > 0.0f) c = texcube_rgb_linear<TILED>(env, env_n, L);  // the shader's mip level is clamped to 0 by the sampler
+                if (NdotL > 0.0f)  // the shader's mip level is clamped to 0 by the sampler
+                    c = LAYOUT == VKR_ENV_LAYOUT_FOOTPRINT_TILES ? texcube_rgb_linear_footprint_tiles((const char *)env, env_n, tiles_per_side, L)
+                                                                 : texcube_rgb_linear<LAYOUT == VKR_ENV_LAYOUT_TILED_4X4>(env, env_n, L);
                 term[t][0][sl] = c.x; term[t][1][sl] = c.y; term[t][2][sl] = c.z; term[t][3][sl] = NdotL;
             }
         }
@@ -1269,25 +1298,79 @@ extern "C" int32_t vkr_ibl_irradiance_by_region_rows(const void *env_tiles, int3
     return launch_status(who);
 }
 
+namespace vkr {
+// Launches the prefilter kernel over `m` (one or more mips) with `group` texels per workgroup.
+static void launch_prefilter(const void *env, int env_n, int env_layout, PrefilterMips &m, int group, hipStream_t s)
+{
+    int per_xcd_total = 0;
+    for (int i = 0; i < m.count; i++) {
+        m.per_xcd[i] = ((m.n_texels[i] + group - 1) / group + 7) / 8;  // groups of texels per XCD
+        per_xcd_total += m.per_xcd[i];
+    }
+    auto kernel = group == 16 ? (env_layout == VKR_ENV_LAYOUT_FOOTPRINT_TILES ? prefilter_texel_kernel<VKR_ENV_LAYOUT_FOOTPRINT_TILES, 16>
+                                 : env_layout == VKR_ENV_LAYOUT_TILED_4X4 ? prefilter_texel_kernel<VKR_ENV_LAYOUT_TILED_4X4, 16> : prefilter_texel_kernel<VKR_ENV_LAYOUT_LINEAR, 16>)
+                             : (env_layout == VKR_ENV_LAYOUT_FOOTPRINT_TILES ? prefilter_texel_kernel<VKR_ENV_LAYOUT_FOOTPRINT_TILES, 2>
+                                 : env_layout == VKR_ENV_LAYOUT_TILED_4X4 ? prefilter_texel_kernel<VKR_ENV_LAYOUT_TILED_4X4, 2> : prefilter_texel_kernel<VKR_ENV_LAYOUT_LINEAR, 2>);
+    hipLaunchKernelGGL(kernel, dim3(8u * (unsigned)per_xcd_total), dim3(256), 0, s, env, env_n, m);
+}
+
+static int32_t check_prefilter_env(const char *who, const void *env, int env_n, int env_layout)
+{
+    VKR_REQUIRE(env && env_n > 0, "%s: the environment is null or its size is bad", who);
+    if (env_layout == VKR_ENV_LAYOUT_FOOTPRINT_TILES) {
+        VKR_REQUIRE(env_n <= 8192 && ((uintptr_t)env & 7u) == 0, "%s: footprint tiles need a face size of at most 8192 and 8-byte alignment", who);
+        return VKR_OK;
+    }
+    return check_env_layout(who, env_n, env_layout);
+}
+}  // namespace vkr
+
 extern "C" int32_t vkr_ibl_prefilter(const void *env, int32_t env_n, int32_t env_layout, void *out, int32_t n, float roughness, int32_t row_begin, int32_t row_end, void *stream)
 {
     using namespace vkr;
-    VKR_REQUIRE(env && out && env_n > 0, "vkr_ibl_prefilter: an image is null or env size is bad");
+    VKR_REQUIRE(out != nullptr, "vkr_ibl_prefilter: the output image is null");
     VKR_REQUIRE(roughness >= 0.0f && roughness <= 1.0f, "vkr_ibl_prefilter: roughness %g outside [0,1]", (double)roughness);
-    int32_t rc = check_rows("vkr_ibl_prefilter", n, 6 * n, row_begin, row_end);
+    int32_t rc = check_prefilter_env("vkr_ibl_prefilter", env, env_n, env_layout);
     if (rc != VKR_OK) return rc;
-    if ((rc = check_env_layout("vkr_ibl_prefilter", env_n, env_layout)) != VKR_OK) return rc;
-    const bool tiled = env_layout == VKR_ENV_LAYOUT_TILED_4X4;
+    if ((rc = check_rows("vkr_ibl_prefilter", n, 6 * n, row_begin, row_end)) != VKR_OK) return rc;
     if ((rc = ensure_tables()) != VKR_OK) return rc;
     if (row_end == row_begin) return VKR_OK;
-    const int n_texels = n * (row_end - row_begin);
-    const int group = n_texels >= 65536 ? 16 : 2;               // output texels per workgroup
-    const int per_xcd = ((n_texels + group - 1) / group + 7) / 8;  // groups of texels per XCD
-    dim3 grid(8 * per_xcd);
-    auto kernel = group == 16 ? (tiled ? prefilter_texel_kernel<true, 16> : prefilter_texel_kernel<false, 16>)
-                             : (tiled ? prefilter_texel_kernel<true, 2> : prefilter_texel_kernel<false, 2>);
-    hipLaunchKernelGGL(kernel, grid, dim3(256), 0, as_stream(stream), env, env_n, (uint2 *)out, n, roughness, row_begin, n_texels, per_xcd);
+    PrefilterMips m = {};
+    m.count = 1; m.out[0] = (uint2 *)out; m.n[0] = n; m.rough[0] = roughness; m.row_begin[0] = row_begin; m.n_texels[0] = n * (row_end - row_begin);
+    launch_prefilter(env, env_n, env_layout, m, m.n_texels[0] >= 65536 ? 16 : 2, as_stream(stream));
     return launch_status("vkr_ibl_prefilter");
+}
+
+extern "C" int32_t vkr_ibl_prefilter_mips(const VkrPrefilterMipsArgs *a, void *stream)
+{
+    using namespace vkr;
+    const char *who = "vkr_ibl_prefilter_mips";
+    VKR_REQUIRE(a != nullptr, "%s: args is null", who);
+    VKR_REQUIRE(a->mips >= 1 && a->mips <= VKR_PREFILTER_MAX_MIPS, "%s: %d mips (1 .. %d)", who, a->mips, VKR_PREFILTER_MAX_MIPS);
+    VKR_REQUIRE(a->base_res > 0 && (a->base_res >> (a->mips - 1)) >= 1, "%s: a base size of %d has no %d mips", who, a->base_res, a->mips);
+    int32_t rc = check_prefilter_env(who, a->env, a->env_res, a->env_layout);
+    if (rc != VKR_OK) return rc;
+    for (int m = 0; m < a->mips; m++) {
+        const int n = a->base_res >> m;
+        VKR_REQUIRE(a->out[m] != nullptr, "%s: the image of mip %d is null", who, m);
+        if ((rc = check_rows(who, n, 6 * n, a->row_begin[m], a->row_end[m])) != VKR_OK) return rc;
+    }
+    if ((rc = ensure_tables()) != VKR_OK) return rc;
+    // a mip with many texels is bound by instruction issue and takes sixteen texels per workgroup in a launch of its own;
+    // the others -- bound by cache-line traffic, and too small to fill the chip one by one -- share one launch
+    PrefilterMips rest = {};
+    for (int m = 0; m < a->mips; m++) {
+        const int n = a->base_res >> m, texels = n * (a->row_end[m] - a->row_begin[m]);
+        if (texels == 0) continue;
+        const float rough = a->mips > 1 ? (float)m / (float)(a->mips - 1) : 0.0f;  // VulkanRenderer.cs:874
+        PrefilterMips one = {};
+        PrefilterMips &dst = texels >= 65536 ? one : rest;
+        const int k = dst.count++;
+        dst.out[k] = (uint2 *)a->out[m]; dst.n[k] = n; dst.rough[k] = rough; dst.row_begin[k] = a->row_begin[m]; dst.n_texels[k] = texels;
+        if (&dst == &one) launch_prefilter(a->env, a->env_res, a->env_layout, one, 16, as_stream(stream));
+    }
+    if (rest.count) launch_prefilter(a->env, a->env_res, a->env_layout, rest, 2, as_stream(stream));
+    return launch_status(who);
 }
 
 extern "C" int32_t vkr_ibl_brdf_lut(void *out, int32_t n, int32_t row_begin, int32_t row_end, void *stream)

@@ -55,21 +55,26 @@ class HipIblBackend:
         self.P.equirect_to_cube(src, src_format, env)
 
     def sampling_copy(self, env):
-        """The cube the irradiance / prefilter passes read: 4x4-texel tiles when the face size allows."""
-        if env.shape[1] % 4 == 0:
-            return self.P.tile_env_cube(env), _lib.ENV_LAYOUT_TILED_4X4
-        return env, _lib.ENV_LAYOUT_LINEAR
+        """The copy of the environment the irradiance and prefilter passes read, as (tensor, layout, face size): footprint
+        tiles (every 2x2 footprint of a LINEAR lookup in one cache line)."""
+        n = env.shape[1]
+        if n <= 8192:
+            return self.P.tile_env_footprints(env), _lib.ENV_LAYOUT_FOOTPRINT_TILES, n
+        return env, _lib.ENV_LAYOUT_LINEAR, n
 
-    def irradiance(self, env, out, rows, env_layout=_lib.ENV_LAYOUT_LINEAR, order=_lib.IRRADIANCE_SEQUENTIAL, linear=None):
-        """`env` in `env_layout` is what the passes sample; `linear` the row-major cube (the rows order makes its own
-        footprint tiles from it).  The by-region orders raise if a texel did not find all of its samples."""
-        if order in (_lib.IRRADIANCE_FASTEST, _lib.IRRADIANCE_BY_REGION_ROWS):
-            self.P.irradiance(env if linear is None else linear, out, order, rows=rows, env_layout=_lib.ENV_LAYOUT_LINEAR)
+    def irradiance(self, sampled, out, rows, order=_lib.IRRADIANCE_FASTEST, linear=None):
+        """`sampled` = sampling_copy(); `linear` the row-major cube, which the orders other than the default one read.
+        The by-region orders raise if a texel did not find all of its samples."""
+        tiles, layout, env_n = sampled
+        if order in (_lib.IRRADIANCE_FASTEST, _lib.IRRADIANCE_BY_REGION_ROWS) and layout == _lib.ENV_LAYOUT_FOOTPRINT_TILES:
+            ws = self.P.irradiance_by_region_rows(tiles, env_n, out, rows)
+            self.P._require_all_samples(ws, "VKR_IRRADIANCE_BY_REGION_ROWS")
         else:
-            self.P.irradiance(env, out, order, rows=rows, env_layout=env_layout)
+            self.P.irradiance(linear, out, order, rows=rows, env_layout=_lib.ENV_LAYOUT_LINEAR)
 
-    def prefilter(self, env, out, roughness, rows, env_layout=_lib.ENV_LAYOUT_LINEAR):
-        self.P.prefilter(env, out, roughness, rows=rows, env_layout=env_layout)
+    def prefilter_mips(self, sampled, cubes, rows):
+        tiles, layout, env_n = sampled
+        self.P.prefilter_mips(tiles, cubes, rows, env_layout=layout, env_n=env_n)
 
     def brdf_lut(self, out, rows):
         self.P.brdf_lut(out, rows=rows)
@@ -105,22 +110,23 @@ class IblPrecompute:
         cfg, be = self.cfg, self.backend
         env = be.empty((6, cfg.env_res, cfg.env_res, 4), torch.float16)
         be.equirect(src, src_format, env)  # replicated
-        sampled, layout = be.sampling_copy(env)
+        sampled = be.sampling_copy(env)
 
         n = cfg.irradiance_res
         irr_flat, irr = self._padded_cube(n)
         r0, r1, per = row_share(6 * n, self.rank, self.world)
-        be.irradiance(sampled, irr, (r0, r1), layout, order=cfg.irradiance_order, linear=env)
+        be.irradiance(sampled, irr, (r0, r1), order=cfg.irradiance_order, linear=env)
         self._all_gather_rows(irr_flat, per)
 
-        mips = []
+        # every mip is split on its own; the rank's shares of all mips go to the device together
+        flats, mips, shares = [], [], []
         for m in range(cfg.prefilter_mips):
             n = cfg.prefilter_res >> m
             flat, cube = self._padded_cube(n)
-            r0, r1, per = row_share(6 * n, self.rank, self.world)
-            be.prefilter(sampled, cube, m / max(cfg.prefilter_mips - 1, 1), (r0, r1), layout)
+            flats.append(flat); mips.append(cube); shares.append(row_share(6 * n, self.rank, self.world))
+        be.prefilter_mips(sampled, mips, [(r0, r1) for r0, r1, _ in shares])
+        for flat, (_, _, per) in zip(flats, shares):
             self._all_gather_rows(flat, per)
-            mips.append(cube)
 
         n = cfg.lut_res
         r0, r1, per = row_share(n, self.rank, self.world)

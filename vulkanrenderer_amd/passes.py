@@ -400,11 +400,40 @@ def irradiance_uncovered(workspace: torch.Tensor, need: int | None = None) -> in
 
 
 def prefilter(env: torch.Tensor, out: torch.Tensor, roughness: float, rows=None,
-              env_layout: int = _lib.ENV_LAYOUT_LINEAR) -> None:
+              env_layout: int = _lib.ENV_LAYOUT_LINEAR, env_n: int | None = None) -> None:
+    """`env`: the cube [6, n, n, 4] row-major or in 4x4 tiles, or (ENV_LAYOUT_FOOTPRINT_TILES) the flat tensor
+    tile_env_footprints() returns, with the face size in `env_n`."""
     lib = _lib.load()
     n = out.shape[1]
     r0, r1 = _rows(6 * n, rows)
-    _lib.check(lib.vkr_ibl_prefilter(_ptr(env), env.shape[1], env_layout, _ptr(out), n, C.c_float(roughness), r0, r1, _stream()))
+    if env_layout == _lib.ENV_LAYOUT_FOOTPRINT_TILES:
+        if env_n is None or env.numel() != lib.vkr_env_footprint_tiles_bytes(env_n):
+            raise ValueError("footprint tiles: pass the face size of the cube they were made from in env_n")
+    else:
+        env_n = env.shape[1]
+    _lib.check(lib.vkr_ibl_prefilter(_ptr(env), env_n, env_layout, _ptr(out), n, C.c_float(roughness), r0, r1, _stream()))
+
+
+def prefilter_mips(env: torch.Tensor, outs: list, rows: list | None = None, env_layout: int = _lib.ENV_LAYOUT_LINEAR,
+                   env_n: int | None = None) -> None:
+    """Every roughness mip of the prefiltered cube (outs[m]: [6, n >> m, n >> m, 4] float16, roughness m / (mips - 1)) in as
+    few launches as serve them best: the images of one prefilter() call per mip.  rows[m] = (begin, end) of mip m's
+    6 (n >> m) rows, default all."""
+    lib = _lib.load()
+    if env_layout == _lib.ENV_LAYOUT_FOOTPRINT_TILES:
+        if env_n is None or env.numel() != lib.vkr_env_footprint_tiles_bytes(env_n):
+            raise ValueError("footprint tiles: pass the face size of the cube they were made from in env_n")
+    else:
+        env_n = env.shape[1]
+    a = _lib.PrefilterMipsArgs()
+    a.env, a.env_res, a.env_layout = _ptr(env), env_n, env_layout
+    a.base_res, a.mips = outs[0].shape[1], len(outs)
+    for m, o in enumerate(outs):
+        if o.shape[1] != a.base_res >> m:
+            raise ValueError(f"mip {m} has face size {o.shape[1]}, expected {a.base_res >> m}")
+        a.out[m] = _ptr(o).value
+        a.row_begin[m], a.row_end[m] = _rows(6 * o.shape[1], None if rows is None else rows[m])
+    _lib.check(lib.vkr_ibl_prefilter_mips(C.byref(a), _stream()))
 
 
 def brdf_lut(out: torch.Tensor, rows=None) -> None:

@@ -86,6 +86,17 @@ def perspective(fov_degrees: float, aspect: float, near: float, far: float) -> n
     return m
 
 
+def reference_light_volume():
+    """The reference's own light-volume mesh -- positions and triangles of assets/models/sphere/sphere.glb
+    (VulkanRenderer.cs:78,269), extracted by tools/make_golden.py --only-light-volume into tests/golden/light_volume.npz:
+    559 vertices (482 positions, repeated along the texture seam), 960 triangles, unit radius, counter-clockwise seen
+    from outside.  Returns (verts [559,3] f32, indices [960,3] u32)."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "light_volume.npz")
+    with np.load(path) as d:
+        return np.ascontiguousarray(d["positions"], dtype=np.float32), np.ascontiguousarray(d["triangles"], dtype=np.uint32)
+
+
 def make_sphere_mesh(segments: int = 32, rings: int = 16):
     """A unit UV sphere with the reference light volume's topology (assets/models/sphere: 32 segments,
     16 rings, 960 triangles), counter-clockwise seen from outside.  Returns (verts [n,3] f32, indices [960,3] u32)."""
