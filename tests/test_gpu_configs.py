@@ -132,6 +132,50 @@ def test_c5_16384_wide_band_with_256_lights(gpu, oracle):
     _check_chain(got, oracle.frame_chain(f), "C5 band")
 
 
+def test_c5_full_width_256_rows_of_the_per_rank_shape(gpu, oracle):
+    """The shape one rank of eight shades in the 16384^2 configuration, at its full width and with all 256 lights and
+    1024^2 cubes (6 GiB, the 64 synthetic cubes repeated), 256 of its 2048 rows -- more than the oracle can check in a
+    test's time, so the whole image is held to properties that do not depend on the size: shaded as one strip and as two
+    strips with halo rows it is the same image byte for byte; the one-kernel post chain equals the three passes; the
+    lights are drawn in four launches of 64 (the kernel's own cut); and a band of 16 rows across the strip boundary equals the oracle's bit for bit."""
+    import dataclasses
+    import torch
+    from vulkanrenderer_amd import passes as P
+    from vulkanrenderer_amd.strips import StripPlan, StripRenderer
+    rows = 256
+    f = _c5_band(rows, 64, 1024, 4)
+    d = P.DeviceFrame.upload(f, gpu)
+    whole = StripRenderer(StripPlan.make(0, 1, rows), 16384, device=gpu)
+    ldr = whole.render(d).clone()
+    color, thr = P.f16_bits(whole.color), P.f16_bits(whole.threshold)
+    # (a) two strips of 128 rows, the halo rows handed over by hand (what the exchange moves), against the one strip
+    parts = []
+    strips = [StripRenderer(StripPlan.make(k, 2, rows), 16384, device=gpu) for k in range(2)]
+    frames = [dataclasses.replace(d, rows=128, albedo=d.albedo[k * 128:(k + 1) * 128], normal=d.normal[k * 128:(k + 1) * 128],
+                                  arm=d.arm[k * 128:(k + 1) * 128], position=d.position[k * 128:(k + 1) * 128]) for k in range(2)]
+    for r, fr in zip(strips, frames):
+        r.backend.shade(fr, r.color, r.threshold)
+    from vulkanrenderer_amd.strips import HALO
+    strips[0].threshold_padded[128 + HALO:] = strips[1].threshold[:HALO]
+    strips[1].threshold_padded[:HALO] = strips[0].threshold[128 - HALO:]
+    for k, r in enumerate(strips):
+        lo, hi = (HALO, 128 + 2 * HALO - 1) if k == 0 else (0, HALO + 128 - 1)
+        r.backend.bloom_post(r.threshold_padded, r.color, r.ldr, lo, hi)
+        parts.append(r.ldr)
+    assert torch.equal(torch.cat(parts, 0), ldr), "two strips with halo rows differ from one strip"
+    # (b) the one-kernel post chain against bloom pass 1, then pass 2 fused with the post-process draw
+    b1 = torch.empty_like(whole.threshold)
+    ldr3 = torch.empty_like(ldr)
+    P.bloom_blur(whole.threshold, b1, True, _lib.WRAP_REPEAT)
+    P.bloomv_postprocess(b1, whole.color, ldr3)
+    assert torch.equal(ldr3, ldr), "the one-kernel post chain differs from its three passes"
+    # (c) rows 120..136 against the oracle (the composition pass is per pixel: a band of the frame is a frame)
+    band = f.rows(120, 136)
+    want_c, want_t = oracle.shade(band)
+    assert_bits_equal(color[120:136], want_c, "C5 rows 120..136: colour")
+    assert_bits_equal(thr[120:136], want_t, "C5 rows 120..136: threshold")
+
+
 W5, H5, L5 = 16384, 72, 6
 
 

@@ -76,24 +76,54 @@ VKR_DEV f3 fetch_src(const void *src, int fmt, int w, int x, int y)
     return mk3(c.r, c.g, c.b);
 }
 
-__global__ __launch_bounds__(256) void equirect_kernel(const void *src, int sw, int sh, int fmt, uint2 *cube, int n, int row_begin, int row_end)
+// atan2 to about 2.5e-7 rad (the error of a correctly rounded result near pi is 1.2e-7): atan(q) on [0, 1] as q P(q^2),
+// P of degree 8 fitted at Chebyshev nodes (1.0e-7), then the octant and the signs.  atan2(0, 0) = 0 like the C
+// library's.  Twenty-odd instructions where the device library's atan2f takes three times as many: the pass was
+// bound by them, not by the 8 bytes per texel it writes.
+VKR_DEV float atan2_short(float y, float x)
 {
-    int i = blockIdx.x * 256 + threadIdx.x;
-    int row = row_begin + blockIdx.y;
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    const float mx = __builtin_fmaxf(ax, ay), mn = __builtin_fminf(ax, ay);
+    const float q = mx > 0.0f ? mn * fast_rcp_rn(mx) : 0.0f;
+    const float t = q * q;
+    float p = fma_(t, 0.0028340642f, -0.01600503f);
+    p = fma_(t, p, 0.042587608f);
+    p = fma_(t, p, -0.07495446f);
+    p = fma_(t, p, 0.10636754f);
+    p = fma_(t, p, -0.14202571f);
+    p = fma_(t, p, 0.19992484f);
+    p = fma_(t, p, -0.33333066f);
+    p = fma_(t, p, 1.0f) * q;
+    p = ay > ax ? 1.57079637f - p : p;
+    p = x < 0.0f ? 3.14159274f - p : p;
+    return __builtin_copysignf(p, y);
+}
+
+// rn = 1 / n as the host's division rounds it (what face_dir computes per texel); the launch has one row of the cube
+// per blockIdx.y.
+__global__ __launch_bounds__(256) void equirect_kernel(const void *src, int sw, int sh, int fmt, uint2 *cube, int n, float rn, int row_begin, int row_end)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int row = row_begin + blockIdx.y;
     if (i >= n || row >= row_end) return;
-    int f = row / n, j = row - f * n;
-    f3 d = normalize3_fast(face_dir(f, i, j, n));
-    float u = fma_(atan2f(d.z, d.x), 0.1591f, 0.5f);
-    float v = 1.0f - fma_(asinf(d.y), 0.3183f, 0.5f);
-    float x = u * (float)sw - 0.5f, y = v * (float)sh - 0.5f;
-    float fx = __builtin_floorf(x), fy = __builtin_floorf(y);
-    float al = x - fx, be = y - fy;
-    // u and v lie in [0, 1], so the four texel coordinates are in [-1, size]: REPEAT is one step, not a division
-    int i0 = wrap_near((int)fx, sw), i1 = wrap_near((int)fx + 1, sw);
-    int j0 = wrap_near((int)fy, sh), j1 = wrap_near((int)fy + 1, sh);
-    float w00 = (1.0f - al) * (1.0f - be), w10 = al * (1.0f - be), w01 = (1.0f - al) * be, w11 = al * be;
-    f3 a = fetch_src(src, fmt, sw, i0, j0), b = fetch_src(src, fmt, sw, i1, j0);
-    f3 c = fetch_src(src, fmt, sw, i0, j1), e = fetch_src(src, fmt, sw, i1, j1);
+    const int f = (int)(((float)row + 0.5f) * rn);  // row / n: exact, rows stay far below 2^22
+    const int j = row - f * n;
+    const float s = fma_((float)(2 * i + 1), rn, -1.0f), t = fma_((float)(2 * j + 1), rn, -1.0f);  // face_dir
+    const f3 d = normalize3_fast(face_point(f, s, t));
+    // asin(d.y) as the angle between the direction and its horizontal part (the direction has unit length)
+    const float u = fma_(atan2_short(d.z, d.x), 0.1591f, 0.5f);
+    const float v = 1.0f - fma_(atan2_short(d.y, fast_sqrt_rn(fma_(d.x, d.x, d.z * d.z))), 0.3183f, 0.5f);
+    const float x = u * (float)sw - 0.5f, y = v * (float)sh - 0.5f;
+    const float fx = __builtin_floorf(x), fy = __builtin_floorf(y);
+    const float al = x - fx, be = y - fy;
+    // u and v lie in [0, 1], so the four texel coordinates are in [-1, size]: REPEAT is one step; the clamp that follows
+    // does nothing for them and keeps anything else (a NaN converts to 0) inside the image
+    const int ix = (int)fx, iy = (int)fy;
+    const int i0 = min(max(ix < 0 ? ix + sw : ix, 0), sw - 1), i1 = min(max(ix + 1 >= sw ? ix + 1 - sw : ix + 1, 0), sw - 1);
+    const int j0 = min(max(iy < 0 ? iy + sh : iy, 0), sh - 1), j1 = min(max(iy + 1 >= sh ? iy + 1 - sh : iy + 1, 0), sh - 1);
+    const float w00 = (1.0f - al) * (1.0f - be), w10 = al * (1.0f - be), w01 = (1.0f - al) * be, w11 = al * be;
+    const f3 a = fetch_src(src, fmt, sw, i0, j0), b = fetch_src(src, fmt, sw, i1, j0);
+    const f3 c = fetch_src(src, fmt, sw, i0, j1), e = fetch_src(src, fmt, sw, i1, j1);
     cube[(size_t)row * n + i] = pack4(fma_(w11, e.x, fma_(w01, c.x, fma_(w10, b.x, w00 * a.x))),
                                       fma_(w11, e.y, fma_(w01, c.y, fma_(w10, b.y, w00 * a.y))),
                                       fma_(w11, e.z, fma_(w01, c.z, fma_(w10, b.z, w00 * a.z))), 1.0f);
@@ -1132,7 +1162,7 @@ extern "C" int32_t vkr_ibl_equirect_to_cube(const void *src, int32_t src_w, int3
     if ((rc = ensure_tables()) != VKR_OK) return rc;
     if (row_end == row_begin) return VKR_OK;
     dim3 grid((n + 255) / 256, row_end - row_begin);
-    hipLaunchKernelGGL(equirect_kernel, grid, dim3(256), 0, as_stream(stream), src, src_w, src_h, src_format, (uint2 *)cube, n, row_begin, row_end);
+    hipLaunchKernelGGL(equirect_kernel, grid, dim3(256), 0, as_stream(stream), src, src_w, src_h, src_format, (uint2 *)cube, n, 1.0f / (float)n, row_begin, row_end);
     return launch_status("vkr_ibl_equirect_to_cube");
 }
 
