@@ -564,6 +564,14 @@ def time_coverage(f, dev_frame, renderer, device) -> dict:
                            "covered_fraction": round(frac, 4),
                            "note": "same lights with colours x0.02: volume radius 16*sqrt(max/5) shrinks to ~1-2.5 units"}
     out["mesh"] = f"the reference's light volume (assets/models/sphere/sphere.glb as arrays, tests/golden/light_volume.npz): {len(verts)} vertices, {len(tris)} triangles"
+    # the rasterising form priced by the bytes it cannot avoid: one 64-bit mask per light and 8x8-pixel tile
+    mask_bytes = len(f.lights) * ((f.width + 7) // 8) * ((f.height + 7) // 8) * 8
+    for key in ("reference_radii_rasterised", "local_lights"):
+        ms = out[key]["coverage_ms"]
+        gbs = mask_bytes / (ms * 1e-3) / 1e9
+        out[key]["roofline"] = dict(kernel="coverage_classify_kernel + coverage_kernel", bound="hbm", algorithmic=f"{mask_bytes} B of masks written", achieved=round(gbs, 1),
+                                    peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 5), avg_launch_ms=ms,
+                                    note="the masks are 4 MB; the time is the binary64 set-up of 960 triangles per (light, 128^2-pixel block), far from any memory bound")
     return out
 
 
@@ -622,12 +630,38 @@ def time_shadow_pass(f, dev_frame, device) -> dict:
     padded_note = "halo rows are not exchanged (one GPU): the post kernel reads whatever the halo rows hold"
     end_to_end = {"whole_frame_ms": from_draws(StripPlan.make(0, 1, f.height)),
                   "rows_of_rank_3_of_8_ms": from_draws(StripPlan.make(3, 8, f.height)), "note": padded_note}
+    point_ms = timed(lambda: P.point_shadow_maps(draws, dev_frame.lights, nl, res))
+    dir_ms = timed(lambda: P.dir_shadow_map(draws, f.scene["light_space_matrix"], dres, device))
+    gpass_ms = timed(lambda: P.gbuffer(gdraws, scene, f.width, f.height, device))
+    sky_ms = timed(lambda: P.skybox(env, scene, f.width, f.height, env_layout=_lib.ENV_LAYOUT_TILED_4X4))
+    cubes, cube_layout = P.point_shadow_maps(draws, dev_frame.lights, nl, res)
+    cube_cov = float((cubes < (25.0 if cube_layout == _lib.CUBE_LAYOUT_TILED_8X4_X25 else 1.0)).float().mean())
+    dmap = P.dir_shadow_map(draws, f.scene["light_space_matrix"], dres, device)
+    gcov = float((ga[..., 3] != 0).float().mean())
+
+    def hbm(kernel, nbytes, ms, algorithmic):
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        return dict(kernel=kernel, bound="hbm", algorithmic=algorithmic, achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                    frac=round(gbs / PEAK_HBM_GBS, 4), avg_launch_ms=round(float(ms), 4))
+    # Rasterising passes, priced by the bytes a pass cannot avoid: every target texel is cleared and every covered one
+    # written at least once more.  Their arithmetic (binary64 edge functions per sample of every triangle's bounding box,
+    # L2 atomics for the depth test) is what the time goes into; the fraction says how far that is from the memory floor.
+    cube_bytes = cubes.numel() * 4
+    px = f.width * f.height
+    roof = [hbm("fill_depth_kernel + point_shadow_kernel", int(cube_bytes * (1 + cube_cov)), point_ms,
+                f"{cube_bytes} B cleared + {cube_cov:.3f} of them written again (covered texels), {len(tris)} triangles x {nl} lights x 6 faces set up"),
+            hbm("fill_depth_kernel + dir_shadow_kernel", int(dmap.numel() * 4 * (1 + float((dmap < 1).float().mean()))), dir_ms,
+                f"{dmap.numel() * 4} B cleared + the covered texels written again"),
+            hbm("gpass_visibility_kernel + gpass_resolve_kernel", int(px * (8 + 8 * gcov + 8 + 32)), gpass_ms,
+                "per pixel: 8 B visibility key reset, written where covered and read back, 32 B of G-buffer written; material texels from cache"),
+            hbm("skybox_kernel", px * 8, sky_ms, "8 B per pixel written; one bilinear cube lookup per pixel from cache")]
     return {"from_draw_calls_end_to_end": end_to_end,
-            "point_shadow_ms": round(timed(lambda: P.point_shadow_maps(draws, dev_frame.lights, nl, res)), 4),
-            "dir_shadow_ms": round(timed(lambda: P.dir_shadow_map(draws, f.scene["light_space_matrix"], dres, device)), 4),
-            "geometry_pass_ms": round(timed(lambda: P.gbuffer(gdraws, scene, f.width, f.height, device)), 4),
-            "geometry_pass_covered_fraction": round(float((ga[..., 3] != 0).float().mean()), 4),
-            "skybox_ms": round(timed(lambda: P.skybox(env, scene, f.width, f.height, env_layout=_lib.ENV_LAYOUT_TILED_4X4)), 4),
+            "point_shadow_ms": round(point_ms, 4), "point_shadow_covered_fraction": round(cube_cov, 4),
+            "dir_shadow_ms": round(dir_ms, 4),
+            "geometry_pass_ms": round(gpass_ms, 4),
+            "geometry_pass_covered_fraction": round(gcov, 4),
+            "skybox_ms": round(sky_ms, 4),
+            "roofline": roof,
             "config": f"{nl} lights x 6 x {res}^2 D32F (written as 8x4 tiles) + {dres}^2 directional map; mesh {len(verts)} vertices, {len(tris)} triangles"}
 
 
