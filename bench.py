@@ -665,7 +665,7 @@ def time_shadow_pass(f, dev_frame, device) -> dict:
             "config": f"{nl} lights x 6 x {res}^2 D32F (written as 8x4 tiles) + {dres}^2 directional map; mesh {len(verts)} vertices, {len(tris)} triangles"}
 
 
-COUNTER_FILE = os.path.join("profiles", "r2_counters.json")
+COUNTER_FILE = os.path.join("profiles", "r3_counters.json")
 
 
 def measured_counters(width: int, rows: int, lights: int, cube_res: int, dir_res: int) -> dict:
@@ -767,7 +767,9 @@ def main() -> None:
     ap.add_argument("--no-extra", action="store_true", help="N > 1: skip the extra shapes (a full strip per rank and the 16384-wide / 256-light strip)")
     ap.add_argument("--extra", action="store_true", help="N = 1: also time the 16384x2048 / 256-light strip (off by default, so that every launch of the "
                     "shading kernel in a default run has the shape the roofline is quoted on and a kernel trace of the run averages one shape)")
-    ap.add_argument("--no-predict", action="store_true", help="skip the predicted strong-scaling table (every strip of the 1/2/4/8-way splits rendered alone)")
+    ap.add_argument("--predict", action="store_true", help="N = 1: add the predicted strong-scaling table for 1, 2, 4, 8 GPUs (every strip of those splits rendered "
+                    "alone on this GPU; off by default for the reason --extra is)")
+    ap.add_argument("--no-predict", action="store_true", help="N > 1: skip the prediction for this N that is printed beside the measured phases")
     ap.add_argument("--transport-only", action="store_true", help="rehearse launcher, halo exchange and gather on CPU tensors (no GPU, no kernels)")
     ap.add_argument("--launch-timeout", type=float, default=900.0, help="seconds the self-started ranks may take")
     args = ap.parse_args()
@@ -933,8 +935,8 @@ def main() -> None:
     }
     if world > 1:
         out["gathered_equals_single_gpu"] = gathered_ok
-    if not args.no_predict:
-        # N = 1: the curve for 1, 2, 4, 8 GPUs; N > 1: this N, to hold beside the measured phases above
+    if (world > 1 and not args.no_predict) or (world == 1 and args.predict):
+        # N > 1: this N, to hold beside the measured phases above; N = 1 (--predict): the curve for 1, 2, 4, 8 GPUs
         note("strips of the N-way splits rendered alone (prediction)")
         out["predicted_strong_scaling"] = predict_strong_scaling(whole, dev_frame, WIDTH, HEIGHT, (1, 2, 4, 8) if world == 1 else (1, world),
                                                                  max(args.steps // 2, 3), device)
