@@ -300,6 +300,51 @@ def predict_strong_scaling(whole, scene_dev, width: int, height: int, worlds, st
     return out
 
 
+def predict_ibl_sharded(worlds, device, reps: int = 3) -> dict:
+    """The IBL precompute at the 2048^2 configuration split over N ranks, predicted from this one GPU: the work of every
+    rank of an N-way split (environment and its tile copy on every rank, the rank's rows of the irradiance cube, of every
+    prefilter mip and of the LUT) is run here alone; the slowest rank sets the time.  The all-gathers (1.2 MB in all) are
+    priced at one small message each.  Unmeasured on hardware."""
+    import torch
+    from vulkanrenderer_amd import _lib, passes as P, synth
+    from vulkanrenderer_amd.ibl import row_share
+    src = P.to_device_f16(synth.make_equirect(np.random.default_rng(SEED + 77), 4096, 2048, hdr=True), device)
+    env = torch.empty((6, 2048, 2048, 4), dtype=torch.float16, device=device)
+    irr = torch.empty((6, 64, 64, 4), dtype=torch.float16, device=device)
+    pres = [torch.empty((6, 128 >> m, 128 >> m, 4), dtype=torch.float16, device=device) for m in range(5)]
+    lut = torch.empty((512, 512, 2), dtype=torch.float16, device=device)
+    box = {}
+
+    def rank_work(rank, world):
+        P.equirect_to_cube(src, _lib.SRC_RGBA16F, env)
+        foot = P.tile_env_footprints(env)
+        r0, r1, _ = row_share(6 * 64, rank, world)
+        box["ws"] = P.irradiance_by_region_rows(foot, 2048, irr, (r0, r1), workspace=box.get(("ws", rank, world)))
+        box[("ws", rank, world)] = box["ws"]
+        P.prefilter_mips(foot, pres, [row_share(6 * (128 >> m), rank, world)[:2] for m in range(5)], env_layout=_lib.ENV_LAYOUT_FOOTPRINT_TILES, env_n=2048)
+        r0, r1, _ = row_share(512, rank, world)
+        P.brdf_lut(lut, (r0, r1))
+
+    out = {}
+    for n in worlds:
+        per_rank = []
+        for k in range(n):
+            rank_work(k, n)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                rank_work(k, n)
+            e1.record()
+            torch.cuda.synchronize()
+            per_rank.append(e0.elapsed_time(e1) / reps)
+        gathers = 7 * XGMI_SMALL_MESSAGE_MS if n > 1 else 0.0  # irradiance, five mips, LUT
+        out[str(n)] = {"rank_ms_slowest": round(max(per_rank), 3), "rank_ms_mean": round(sum(per_rank) / n, 3), "all_gathers_ms_assumed": round(gathers, 3),
+                       "predicted_ms": round(max(per_rank) + gathers, 3)}
+    out["note"] = "predicted from one GPU running each rank's share alone; the environment (0.13 ms) and its tile copy (0.16 ms) are made on every rank; unmeasured on hardware"
+    return out
+
+
 def kernel_times(renderer, dev_frame, rows: int, steps: int) -> dict:
     """Average duration of the two kernels of a step (shade; both bloom passes + post-process as one kernel), each
     between two HIP events on the launch stream, and of the three-pass form of the post chain the one kernel
@@ -940,6 +985,8 @@ def main() -> None:
         note("strips of the N-way splits rendered alone (prediction)")
         out["predicted_strong_scaling"] = predict_strong_scaling(whole, dev_frame, WIDTH, HEIGHT, (1, 2, 4, 8) if world == 1 else (1, world),
                                                                  max(args.steps // 2, 3), device)
+        if not args.no_ibl:
+            out["predicted_ibl_precompute_sharded"] = predict_ibl_sharded((1, 2, 4, 8) if world == 1 else (1, world), device)
     out.update(extra)
     if world == 1 and dev_frame.cube_layout != 0:
         rt = time_shadow_retile(f, device)
