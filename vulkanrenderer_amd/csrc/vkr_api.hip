@@ -418,6 +418,7 @@ extern "C" int32_t vkr_create(const VkrConfig *config, vkr_ctx **out)
     VKR_REQUIRE(cfg.max_lights > 0 && cfg.frames_in_flight > 0 && cfg.frames_in_flight <= 8, "vkr_create: bad max_lights / frames_in_flight");
     VKR_REQUIRE(cfg.dir_shadow_res > 0 && cfg.dir_shadow_res <= 32768 && cfg.point_shadow_res > 0 && cfg.point_shadow_res <= 8192, "vkr_create: bad shadow map size");
     VKR_REQUIRE(cfg.env_res > 0 && cfg.irradiance_res > 0 && cfg.prefilter_res > 0 && cfg.brdf_lut_res > 0, "vkr_create: bad IBL size");
+    VKR_REQUIRE(cfg.env_res <= 8192 && cfg.irradiance_res <= 4096, "vkr_create: environment faces of at most 8192^2 and irradiance faces of at most 4096^2 are supported (%d, %d)", cfg.env_res, cfg.irradiance_res);
     VKR_REQUIRE(cfg.prefilter_mips <= VKR_PREFILTER_MAX_MIPS, "vkr_create: %d prefilter mips; at most %d are supported", cfg.prefilter_mips, VKR_PREFILTER_MAX_MIPS);
     VKR_REQUIRE(cfg.prefilter_mips > 0 && (cfg.prefilter_res >> (cfg.prefilter_mips - 1)) > 0, "vkr_create: %d mips do not fit a %d^2 prefilter cube", cfg.prefilter_mips, cfg.prefilter_res);
 
