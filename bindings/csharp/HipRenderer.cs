@@ -105,7 +105,7 @@ public sealed unsafe class HipRenderer : IDisposable
 
     // VKR_ABI_VERSION of the vkr_hip.h these declarations were written against: a library of another revision
     // would misread the structs passed below
-    public const int AbiVersion = 3;
+    public const int AbiVersion = 4;
 
     public HipRenderer(in VkrConfig config)
     {

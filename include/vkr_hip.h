@@ -124,7 +124,7 @@ typedef struct VkrLightInfo {
  * History: 1 the first interface; 2 VkrShadeArgs.coverage_flags, VkrCoverageArgs.light_flags,
  * VkrConfig.frame_rows / row0, VKR_CUBE_LAYOUT_TILED_8X4 stores its tiles column by column;
  * 3 VKR_IRRADIANCE_BY_REGION_ROWS and the layer-2 default order, the workspace word of the by-region call. */
-#define VKR_ABI_VERSION 3
+#define VKR_ABI_VERSION 4
 VKR_EXPORT const char *vkr_last_error(void);
 VKR_EXPORT int32_t vkr_abi_version(void);
 /* Number of gfx950 devices visible to the process (0 if none); never fails. */
@@ -157,8 +157,19 @@ typedef struct VkrShadeArgs {
     const uint32_t *coverage_flags;               /* VKR_COVERAGE_MESH: VkrCoverageArgs.light_flags of the call that wrote
                                                      coverage_masks, or NULL; when it says that every light covers every
                                                      pixel the masks are not read */
+    const void *cube_ranges;                      /* depth ranges of cube_shadow written by vkr_cube_shadow_ranges(), or NULL:
+                                                     same output either way, fewer shadow-map fetches with them */
 } VkrShadeArgs;
 VKR_EXPORT int32_t vkr_shade(const VkrShadeArgs *args, void *stream);
+
+/* Depth ranges of the cube shadow maps, an acceleration structure for vkr_shade with no counterpart in the reference
+ * (light.frag:131-137 reads its 20 taps per light unconditionally): the smallest and largest value the taps compare
+ * against over half-overlapping blocks of each face, at four block sizes.  Where one range shows that all 20 taps of a
+ * pixel are in shadow, or none, vkr_shade takes that count without reading the taps; the image is the same bit for bit.
+ * `ranges` is device memory of vkr_cube_shadow_ranges_bytes(n_lights, res) bytes; rebuild it whenever `cubes` changes.
+ * `layout` is the VKR_CUBE_LAYOUT_* of `cubes`. */
+VKR_EXPORT int64_t vkr_cube_shadow_ranges_bytes(int32_t n_lights, int32_t res);
+VKR_EXPORT int32_t vkr_cube_shadow_ranges(const float *cubes, int32_t n_lights, int32_t res, int32_t layout, void *ranges, void *stream);
 
 /* Which pixels the light.frag draw of each light touches: the light-volume mesh (the reference's
  * unit sphere, assets/models/sphere/sphere.glb, or any closed mesh) is placed by each light's model

@@ -1,0 +1,132 @@
+"""Depth ranges of the point-shadow cubes (vkr_cube_shadow_ranges) and the shading kernel's use of them.
+
+The ranges are an acceleration structure the reference does not have: light.frag:131-137 reads its 20 taps for
+every light of every pixel.  With ranges the kernel replaces the taps by their known outcome where one range shows that
+all 20 comparisons agree.  Bars: every range is the exact minimum and maximum (binary32) of the comparison values
+of its block; the shaded image is the oracle's, bit for bit, with ranges and without."""
+import dataclasses
+
+import numpy as np
+import pytest
+
+from vulkanrenderer_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+CELL, LEVELS = 16, 4
+
+
+def _block_extremes(cube25: np.ndarray, level: int):
+    """cube25 [6, res, res] comparison values -> (lo, hi) [6, blocks, blocks] of the blocks of 2S x 2S texels at
+    stride S = CELL << level, cut at the face's edge; a block with a NaN is (-inf, +inf)."""
+    res = cube25.shape[-1]
+    s = CELL << level
+    blocks = (res + s - 1) // s
+    lo = np.empty((6, blocks, blocks), np.float32)
+    hi = np.empty_like(lo)
+    for by in range(blocks):
+        for bx in range(blocks):
+            w = cube25[:, by * s:by * s + 2 * s, bx * s:bx * s + 2 * s].reshape(6, -1)
+            nan = np.isnan(w).any(axis=1)
+            lo[:, by, bx] = np.where(nan, -np.inf, np.nanmin(np.where(np.isnan(w), np.inf, w), axis=1))
+            hi[:, by, bx] = np.where(nan, np.inf, np.nanmax(np.where(np.isnan(w), -np.inf, w), axis=1))
+    return lo, hi
+
+
+@pytest.mark.parametrize("res,layout", [(64, _lib.CUBE_LAYOUT_LINEAR), (64, _lib.CUBE_LAYOUT_TILED_8X4), (64, _lib.CUBE_LAYOUT_TILED_8X4_X25),
+                                        (24, _lib.CUBE_LAYOUT_TILED_8X4_X25), (100, _lib.CUBE_LAYOUT_LINEAR), (7, _lib.CUBE_LAYOUT_LINEAR),
+                                        (272, _lib.CUBE_LAYOUT_TILED_8X4_X25), (512, _lib.CUBE_LAYOUT_TILED_8X4_X25)])
+def test_ranges_are_the_extremes_of_their_blocks(gpu, res, layout):
+    import torch
+    from vulkanrenderer_amd import passes as P
+    rng = np.random.default_rng(res * 10 + layout)
+    n_lights = 3
+    cubes = rng.uniform(0.02, 0.9, (n_lights, 6, res, res)).astype(np.float32)
+    cubes[0] = synth.make_cube_shadows(rng, 1, res)[0]          # a smooth one: narrow ranges
+    cubes[1, 2, res // 3, res // 2] = np.nan                    # a NaN poisons the blocks that hold it
+    cubes[2, 4, 0, 0] = np.inf
+    dev = torch.from_numpy(cubes).to(gpu)
+    stored = dev if layout == _lib.CUBE_LAYOUT_LINEAR else P.tile_depth_cubes(dev, layout)
+    got = P.cube_shadow_ranges(stored, layout).cpu().numpy().view(np.float32)
+    cells = (res + CELL - 1) // CELL
+    got = got.reshape(n_lights, LEVELS + 1, 6, cells, cells, 2)
+    cmp = (cubes * np.float32(25.0)).astype(np.float32)         # the product every tap forms, in binary32
+    for li in range(n_lights):
+        for level in range(LEVELS):
+            lo, hi = _block_extremes(cmp[li], level)
+            b = lo.shape[-1]
+            assert np.array_equal(got[li, level, :, :b, :b, 0], lo), (li, level)
+            assert np.array_equal(got[li, level, :, :b, :b, 1], hi), (li, level)
+            pad = np.ones((cells, cells), bool); pad[:b, :b] = False
+            assert np.all(got[li, level, :, pad, 0] == -np.inf) and np.all(got[li, level, :, pad, 1] == np.inf)
+    assert np.isinf(got[1, 0, 2]).any() and not np.isinf(got[0, 0]).any()
+
+
+def _shade(P, torch, frame, gpu):
+    color = torch.empty((frame.rows, frame.width, 4), dtype=torch.float16, device=gpu)
+    thr = torch.empty_like(color)
+    P.shade(frame, color, thr)
+    torch.cuda.synchronize()
+    return P.f16_bits(color), P.f16_bits(thr)
+
+
+def _blocky_cubes(rng, n_lights, res):
+    """Depth cubes with plateaus and jumps (what rendered geometry leaves), some blocks at the clear value."""
+    out = np.empty((n_lights, 6, res, res), np.float32)
+    for i in range(n_lights):
+        step = int(rng.choice([4, 16, 48]))
+        n = (res + step - 1) // step
+        coarse = rng.uniform(1.0, 7.0, (6, n, n)).astype(np.float32)
+        coarse[rng.random((6, n, n)) < 0.2] = 25.0
+        out[i] = (coarse.repeat(step, 1).repeat(step, 2)[:, :res, :res] + 0.05 * synth._smooth_field(rng, res, 8, 6)) / 25.0
+    return out
+
+
+@pytest.mark.parametrize("seed,w,h,nl,res,tiled", [(31, 320, 200, 6, 256, None), (32, 200, 120, 4, 512, True), (33, 160, 96, 5, 100, False),
+                                                   (34, 96, 64, 70, 64, None)])
+def test_shade_with_ranges_equals_the_oracle_and_the_kernel_without(gpu, oracle, seed, w, h, nl, res, tiled):
+    import torch
+    from vulkanrenderer_amd import passes as P
+    f = synth.make_frame(seed, w, h, nl, res, 128, irr_res=8, pref_res=16, lut_res=32)
+    if seed % 2 == 0:
+        f.cube_shadow = _blocky_cubes(np.random.default_rng(seed), nl, res)
+    d = P.DeviceFrame.upload(f, gpu, tiled=tiled)
+    assert d.cube_ranges is not None
+    with_ranges = _shade(P, torch, d, gpu)
+    without = _shade(P, torch, dataclasses.replace(d, cube_ranges=None), gpu)
+    want = oracle.shade(f)
+    for got, other, ref, name in zip(with_ranges, without, want, ("color", "threshold")):
+        assert np.array_equal(got, other), name
+        assert np.array_equal(got, ref), name
+
+
+def test_shade_with_ranges_over_maps_with_nan_and_infinite_texels(gpu, oracle):
+    """NaN texels compare as not closer in every tap; a block holding one settles nothing and its taps are read."""
+    import torch
+    from vulkanrenderer_amd import passes as P
+    f = synth.make_frame(41, 192, 128, 4, 128, 64, irr_res=8, pref_res=16, lut_res=32)
+    rng = np.random.default_rng(41)
+    c = f.cube_shadow.copy()
+    holes = rng.random(c.shape) < 0.002
+    c[holes] = np.nan
+    c[rng.random(c.shape) < 0.002] = np.inf
+    c[rng.random(c.shape) < 0.002] = -np.inf
+    f.cube_shadow = c
+    d = P.DeviceFrame.upload(f, gpu)
+    got = _shade(P, torch, d, gpu)
+    want = oracle.shade(f)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
+def test_ranges_follow_the_cubes_they_were_built_from(gpu):
+    """Stale ranges are the caller's to avoid: rebuilding after the cubes change gives the image of the new cubes."""
+    import torch
+    from vulkanrenderer_amd import passes as P
+    f = synth.make_frame(51, 160, 96, 3, 64, 64, irr_res=8, pref_res=16, lut_res=32)
+    d = P.DeviceFrame.upload(f, gpu)
+    f2 = dataclasses.replace(f, cube_shadow=_blocky_cubes(np.random.default_rng(5), 3, 64))
+    d2 = P.DeviceFrame.upload(f2, gpu)
+    d.cube_shadow.copy_(d2.cube_shadow)
+    P.cube_shadow_ranges(d.cube_shadow, d.cube_layout, d.cube_ranges)
+    a, b = _shade(P, torch, d, gpu), _shade(P, torch, dataclasses.replace(d2, cube_ranges=None), gpu)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VKR_HIP_LIB") or os.path.join(_HERE, "libvkr_hip.so")
 
 VKR_OK = 0
-ABI_VERSION = 3  # VKR_ABI_VERSION of include/vkr_hip.h as this binding was written against
+ABI_VERSION = 4  # VKR_ABI_VERSION of include/vkr_hip.h as this binding was written against
 VKR_ERR_INVALID, VKR_ERR_HIP, VKR_ERR_UNSUPPORTED, VKR_ERR_ORDER, VKR_ERR_NO_DEVICE = -1, -2, -3, -4, -5
 COVERAGE_FULLSCREEN, COVERAGE_MESH = 0, 1
 CUBE_LAYOUT_LINEAR, CUBE_LAYOUT_TILED_8X4, CUBE_LAYOUT_TILED_8X4_X25 = 0, 1, 2
@@ -65,7 +65,8 @@ class ShadeArgs(C.Structure):
                 ("irradiance", C.c_void_p), ("irr_res", C.c_int32),
                 ("prefilter", C.c_void_p), ("pref_res", C.c_int32),
                 ("brdf_lut", C.c_void_p), ("lut_res", C.c_int32),
-                ("out_color", C.c_void_p), ("out_threshold", C.c_void_p), ("coverage_flags", C.c_void_p)]
+                ("out_color", C.c_void_p), ("out_threshold", C.c_void_p), ("coverage_flags", C.c_void_p),
+                ("cube_ranges", C.c_void_p)]
 
 
 class CoverageArgs(C.Structure):
@@ -157,6 +158,8 @@ PROTOTYPES = {
     "vkr_shade": [C.POINTER(ShadeArgs), _vp],
     "vkr_tile_depth_cubes": [_vp, _vp, C.c_int32, C.c_int32, _vp],
     "vkr_relayout_depth_cubes": [_vp, _vp, _i32, _i32, _i32, _vp],
+    "vkr_cube_shadow_ranges_bytes": [_i32, _i32],
+    "vkr_cube_shadow_ranges": [_vp, _i32, _i32, _i32, _vp, _vp],
     "vkr_light_coverage": [C.POINTER(CoverageArgs), _vp],
     "vkr_point_shadow_maps": [C.POINTER(PointShadowArgs), _vp],
     "vkr_gbuffer": [C.POINTER(GpassArgs), _vp],
@@ -229,7 +232,8 @@ _lib = None
 
 
 RETURNS_INT64 = {"vkr_gbuffer_workspace_bytes", "vkr_ibl_irradiance_by_region_workspace_bytes",
-                 "vkr_ibl_irradiance_by_region_rows_workspace_bytes", "vkr_env_footprint_tiles_bytes"}
+                 "vkr_ibl_irradiance_by_region_rows_workspace_bytes", "vkr_env_footprint_tiles_bytes",
+                 "vkr_cube_shadow_ranges_bytes"}
 
 
 def load() -> C.CDLL:

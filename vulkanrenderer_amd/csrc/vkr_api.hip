@@ -29,6 +29,8 @@ struct Frame {
     bool has_background = false;
     float *dir_shadow = nullptr;
     float *cube_shadow = nullptr;
+    void *cube_ranges = nullptr;  // depth ranges of cube_shadow (vkr_cube_shadow_ranges), rebuilt before a composition pass
+    int ranges_lights = 0;        // how many lights' ranges are current; 0 after any change of the cubes
     VkrLightInfo *lights = nullptr;
     int n_lights = 0;
     int coverage = VKR_COVERAGE_FULLSCREEN;
@@ -146,6 +148,7 @@ static int32_t clear_shadow_maps(vkr_ctx *c)
     for (Frame &f : c->frames) {
         int32_t rc = fill_u64(f.dir_shadow, dir / 2, D32F_ONE_PAIR, c->stream);
         if (rc == VKR_OK) rc = fill_u64(f.cube_shadow, cube / 2, c->cubes_tiled ? D32F_25_PAIR : D32F_ONE_PAIR, c->stream);
+        f.ranges_lights = 0;
         if (rc != VKR_OK) return rc;
         const float one = 1.0f;  // a map with an odd number of texels: the last one
         if (dir & 1) VKR_HIP_CHECK(hipMemcpyAsync(f.dir_shadow + dir - 1, &one, 4, hipMemcpyHostToDevice, c->stream));
@@ -164,6 +167,7 @@ static void destroy(vkr_ctx *c)
     for (Frame &f : c->frames) {
         if (f.dir_shadow) (void)hipFree(f.dir_shadow);
         if (f.cube_shadow) (void)hipFree(f.cube_shadow);
+        if (f.cube_ranges) (void)hipFree(f.cube_ranges);
         if (f.lights) (void)hipFree(f.lights);
     }
     void *ibl[] = {c->env, c->env_tiled, c->env_foot, c->irradiance, c->brdf_lut, c->cube_staging, c->mesh_verts, c->mesh_indices};
@@ -220,6 +224,7 @@ static int32_t fill_shade_args(vkr_ctx *c, Frame &f, VkrShadeArgs &a)
     a.dir_shadow = f.dir_shadow; a.dir_res = c->cfg.dir_shadow_res;
     a.cube_shadow = f.cube_shadow; a.cube_res = c->cfg.point_shadow_res;
     a.cube_layout = c->cubes_tiled ? VKR_CUBE_LAYOUT_TILED_8X4_X25 : VKR_CUBE_LAYOUT_LINEAR;
+    a.cube_ranges = f.n_lights > 0 ? f.cube_ranges : nullptr;  // brought up to date by shade() below
     a.irradiance = c->irradiance; a.irr_res = c->cfg.irradiance_res;
     a.prefilter = c->prefilter[0]; a.pref_res = c->cfg.prefilter_res;
     a.brdf_lut = c->brdf_lut; a.lut_res = c->cfg.brdf_lut_res;
@@ -227,6 +232,18 @@ static int32_t fill_shade_args(vkr_ctx *c, Frame &f, VkrShadeArgs &a)
     a.coverage_masks = f.coverage == VKR_COVERAGE_MESH ? f.coverage_buf : nullptr;
     a.coverage_flags = f.coverage == VKR_COVERAGE_MESH && c->mesh_closed ? coverage_flags(c, f) : nullptr;
     return VKR_OK;
+}
+
+// The composition pass proper: the depth ranges of the point-shadow cubes are rebuilt first when the cubes changed
+// since they were last built (a shadow pass ran, a cube was uploaded or cleared) or more lights are in use.
+static int32_t shade(vkr_ctx *c, Frame &f, const VkrShadeArgs &a)
+{
+    if (f.ranges_lights < f.n_lights) {
+        const int32_t rc = vkr_cube_shadow_ranges(f.cube_shadow, f.n_lights, a.cube_res, a.cube_layout, f.cube_ranges, c->stream);
+        if (rc != VKR_OK) return rc;
+        f.ranges_lights = f.n_lights;
+    }
+    return vkr_shade(&a, c->stream);
 }
 
 static constexpr int GP_MAX_DRAWS = 1024;  // draw records the geometry-pass workspace has room for
@@ -282,6 +299,7 @@ static int32_t run_point_shadows(vkr_ctx *c, Frame &f)
     ps.res = c->cfg.point_shadow_res; ps.far_plane = 25.0f;  // VulkanRenderer.cs:331
     ps.layout = c->cubes_tiled ? VKR_CUBE_LAYOUT_TILED_8X4_X25 : VKR_CUBE_LAYOUT_LINEAR;
     ps.out = f.cube_shadow;
+    f.ranges_lights = 0;
     return vkr_point_shadow_maps(&ps, c->stream);
 }
 
@@ -444,6 +462,7 @@ extern "C" int32_t vkr_create(const VkrConfig *config, vkr_ctx **out)
             memset(&f.scene, 0, sizeof(f.scene));
             VKR_HIP_CHECK(hipMalloc((void **)&f.dir_shadow, (size_t)cfg.dir_shadow_res * cfg.dir_shadow_res * 4));
             VKR_HIP_CHECK(hipMalloc((void **)&f.cube_shadow, (size_t)cfg.max_lights * 6 * cfg.point_shadow_res * cfg.point_shadow_res * 4));
+            VKR_HIP_CHECK(hipMalloc(&f.cube_ranges, (size_t)vkr_cube_shadow_ranges_bytes(cfg.max_lights, cfg.point_shadow_res)));
             VKR_HIP_CHECK(hipMalloc((void **)&f.lights, (size_t)cfg.max_lights * sizeof(VkrLightInfo)));
         }
         c->cubes_tiled = cfg.point_shadow_res % 8 == 0;
@@ -686,6 +705,7 @@ extern "C" int32_t vkr_upload_point_shadow(vkr_ctx *c, int32_t light, const floa
     VKR_REQUIRE(light >= 0 && light < c->cfg.max_lights, "vkr_upload_point_shadow: light %d outside [0,%d)", light, c->cfg.max_lights);
     size_t per = (size_t)6 * c->cfg.point_shadow_res * c->cfg.point_shadow_res;
     float *dst = c->frames[c->frame].cube_shadow + per * light;
+    c->frames[c->frame].ranges_lights = 0;
     if (!c->cubes_tiled) return upload(c, dst, depth_cube, per * 4);
     // host rows -> staging -> 8x4-texel tiles (what the shade kernel's gathers are laid out for)
     VKR_HIP_CHECK(hipMemcpyAsync(c->cube_staging, depth_cube, per * 4, hipMemcpyHostToDevice, c->stream));
@@ -819,7 +839,7 @@ extern "C" int32_t vkr_pass_composition(vkr_ctx *c)
     if ((rc = run_geometry_pass(c, c->frames[c->frame])) != VKR_OK) return rc;
     if ((rc = run_coverage(c, c->frames[c->frame])) != VKR_OK) return rc;
     if ((rc = run_skybox(c, c->frames[c->frame])) != VKR_OK) return rc;
-    return vkr_shade(&a, c->stream);
+    return shade(c, c->frames[c->frame], a);
 }
 
 extern "C" int32_t vkr_pass_bloom(vkr_ctx *c, int32_t horizontal)
@@ -937,6 +957,7 @@ static int32_t clear_stage_attachments(vkr_ctx *c, Frame &f, int32_t stage)
     switch (stage) {
     case VKR_STAGE_POINT_SHADOW: {
         const size_t cube = (size_t)c->cfg.max_lights * 6 * c->cfg.point_shadow_res * c->cfg.point_shadow_res;  // even: 6 faces
+        f.ranges_lights = 0;
         return fill_u64(f.cube_shadow, cube / 2, c->cubes_tiled ? D32F_25_PAIR : D32F_ONE_PAIR, c->stream);
     }
     case VKR_STAGE_DIR_SHADOW: {
@@ -976,7 +997,7 @@ static int32_t run_stage(vkr_ctx *c, Frame &f, int32_t stage)
         if ((rc = fill_shade_args(c, f, a)) != VKR_OK) return rc;
         if ((rc = run_coverage(c, f)) != VKR_OK) return rc;
         if ((rc = run_skybox(c, f)) != VKR_OK) return rc;
-        return vkr_shade(&a, c->stream);
+        return shade(c, f, a);
     }
     case VKR_STAGE_BLOOM1: return vkr_pass_bloom(c, 1);
     case VKR_STAGE_BLOOM2: return vkr_pass_bloom(c, 0);
@@ -1035,7 +1056,7 @@ extern "C" int32_t vkr_strip_shade(vkr_ctx *c)
     if ((rc = run_geometry_pass(c, f)) != VKR_OK) return rc;
     if ((rc = run_coverage(c, f)) != VKR_OK) return rc;  // counted with the composition pass in the timing, like the skybox
     if ((rc = run_skybox(c, f)) != VKR_OK) return rc;
-    if ((rc = vkr_shade(&a, c->stream)) != VKR_OK) return rc;
+    if ((rc = shade(c, f, a)) != VKR_OK) return rc;
     VKR_HIP_CHECK(hipEventRecord(c->ev[1], c->stream));
     VKR_HIP_CHECK(hipEventRecord(c->ev_shaded, c->stream));
     c->strip_shaded = true;

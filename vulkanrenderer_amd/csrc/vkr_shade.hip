@@ -36,6 +36,8 @@ struct ShadeParams {
     uint2 *out_color, *out_threshold;
     const unsigned long long *coverage;  // per (light, 8x8 tile) masks, or null
     const unsigned *coverage_flags;      // with masks: word n_lights = number of lights that do not cover every pixel; or null
+    const float2 *cube_ranges;           // depth ranges of blocks of the cube maps (see cube_ranges_* below), or null
+    unsigned range_cells;                // ceil(cube_res / RANGE_CELL)
     float cam[3];
     float dir_dir[3];
     float dir_color[3];
@@ -230,6 +232,52 @@ VKR_DEV float taps_one_face(const float *face_base, int res, const float (&X)[3]
     VKR_GRID20B(VKR_TAP)
 #undef VKR_TAP
     return count + count_a;  // an integer in [0, 20], exact in binary32
+}
+
+// Depth ranges of the cube maps: a coarse image beside each face that lets most lights of most waves be settled by one
+// fetch instead of twenty.  Level k (0..RANGE_LEVELS-1) holds, for every block of 2S x 2S texels at stride S = RANGE_CELL << k
+// in both directions (block (bx, by) covers columns [bx S, bx S + 2S) and rows [by S, by S + 2S), cut at the face's edge),
+// the smallest and the largest of the values the taps compare against (25 x depth, rounded as the taps round it).  Blocks
+// overlap by half, so a window of texels no wider than S lies inside the block that holds its first column and row.
+// A block with a NaN in it holds (-inf, +inf) and settles nothing.
+// Memory: [light][level][face][cells][cells] pairs of floats with cells = ceil(res / RANGE_CELL) at every level (rows
+// and slabs of the coarser levels are padded to the size of level 0, which keeps the address arithmetic uniform).
+static constexpr int RANGE_CELL = 16, RANGE_LEVELS = 4;
+
+// The one-face case again: are the 20 comparisons of this lane all true, or all false?  A tap's column is
+// floor(t) for t = (u / m) h + h evaluated in binary32 (h = res / 2), with u within r of the centre's u0 and |m| within
+// r of the centre's |m0|: in exact arithmetic |t - t0| <= HW = h r (1 + |u0 / m0|) / (|m0| - r), and three roundings of
+// relative size 2^-24 move a t of at most 2^13 by less than 2^-9, so every tap column lies within floor(HW) + 3 of the
+// centre's own column as computed here from hardware reciprocals (one more unit in the last place, the same argument);
+// rows likewise.  `hr` is h r (1 + 2^-8), the margin that covers the roundings of this bound itself.  The window of
+// half-width hw around the centre, cut at the face's edge, is less than S = 16 << level wide for level = bits(hw >> 3),
+// so the block of that level that holds its first column and row covers it.  One range over that block then bounds
+// every texel a tap can read: cur > largest means 20 taps in shadow, not (cur > smallest) means none -- the very
+// comparison of step_closer.  Returns whether the lane is settled and, if so, its count (0 or 20) in `count`.
+template <int AXIS, bool POW2>
+VKR_DEV bool taps_settled_by_ranges(const float2 *face_ranges, unsigned cells, int res, float fx, float fy, float fz, float r, float hr, float cur, float &count)
+{
+    const float fres = (float)res;
+    const float m0 = AXIS == 2 ? fz : (AXIS == 1 ? fy : fx);
+    const float rs = __builtin_amdgcn_rcpf(m0), ru = __builtin_fabsf(rs);
+    float u, ur, w, wr;  // the face coordinates of the centre, by the rules of taps_one_face
+    if (AXIS == 2) { u = fx; ur = rs; w = -fy; wr = ru; }
+    else if (AXIS == 1) { u = fx; ur = ru; w = fz; wr = rs; }
+    else { u = -fz; ur = rs; w = -fy; wr = ru; }
+    const float qu = u * ur, qw = w * wr;
+    const int ci = face_texel_inside<POW2>(u, ur, fres), cj = face_texel_inside<POW2>(w, wr, fres);
+    const float k = hr * __builtin_amdgcn_rcpf(__builtin_fabsf(m0) - r), k3 = k + 3.0f;
+    const float hwf = __builtin_fmaxf(fma_(__builtin_fabsf(qu), k, k3), fma_(__builtin_fabsf(qw), k, k3));
+    int hw;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(hw) : "v"(__builtin_fminf(hwf, 0x1p20f)));
+    const unsigned level = 32u - (unsigned)__clz(hw >> 3);                // smallest k with 2 hw < 16 << k
+    const unsigned shift = 4u + level;
+    const unsigned i_lo = (unsigned)max(ci - hw, 0), j_lo = (unsigned)max(cj - hw, 0);
+    const unsigned slab = min(level, (unsigned)RANGE_LEVELS - 1u) * 6u;   // an unsettled lane still reads inside the array
+    const float2 range = face_ranges[__umul24(__umul24(slab, cells) + (j_lo >> shift), cells) + (i_lo >> shift)];
+    const bool all_closer = cur > range.y, none_closer = !(cur > range.x);
+    count = all_closer ? 20.0f : 0.0f;
+    return level < (unsigned)RANGE_LEVELS && (all_closer || none_closer);
 }
 
 // The count for a wave that straddles a cube edge or corner: the face is chosen per tap and per lane
@@ -491,6 +539,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     if (!degenerate_normal) {
         const float disk = fma_(view_distance, 1.0f / 25.0f, 1.0f) * (1.0f / 25.0f);
         const float fourNdotV = 4.0f * NdotV;
+        const float range_hr = (0.5f * (float)p.cube_res * (1.0f + 0x1p-8f)) * disk;  // see taps_settled_by_ranges
         const size_t face_stride = (size_t)p.cube_res * p.cube_res;
         auto rcp_fast = [](float v) { return fast_rcp_rn(v); };
         // Light records are read-only for the whole launch and their address is wave-uniform: read
@@ -561,10 +610,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             const int face0 = wave_common_face(Fv.x, Fv.y, Fv.z, disk);
             float count;
             if (face0 >= 0) {
-                const float *fb = cube + (size_t)face0 * face_stride;
-                if (face0 >= 4) count = taps_one_face<2, TILED, POW2, X25>(fb, p.cube_res, X, Y, Z, cur);
-                else if (face0 >= 2) count = taps_one_face<1, TILED, POW2, X25>(fb, p.cube_res, X, Y, Z, cur);
-                else count = taps_one_face<0, TILED, POW2, X25>(fb, p.cube_res, X, Y, Z, cur);
+                bool settled = false;
+                if (p.cube_ranges) {  // one fetch of a depth range may stand for the 20 taps, for every lane that matters
+                    const float2 *fr = p.cube_ranges + ((size_t)li * ((RANGE_LEVELS + 1) * 6) + face0) * p.range_cells * p.range_cells;
+                    bool lane_settled;
+                    if (face0 >= 4) lane_settled = taps_settled_by_ranges<2, POW2>(fr, p.range_cells, p.cube_res, Fv.x, Fv.y, Fv.z, disk, range_hr, cur, count);
+                    else if (face0 >= 2) lane_settled = taps_settled_by_ranges<1, POW2>(fr, p.range_cells, p.cube_res, Fv.x, Fv.y, Fv.z, disk, range_hr, cur, count);
+                    else lane_settled = taps_settled_by_ranges<0, POW2>(fr, p.range_cells, p.cube_res, Fv.x, Fv.y, Fv.z, disk, range_hr, cur, count);
+                    settled = (live & ~__builtin_amdgcn_ballot_w64(lane_settled)) == 0ull;
+                }
+                if (!settled) {
+                    const float *fb = cube + (size_t)face0 * face_stride;
+                    if (face0 >= 4) count = taps_one_face<2, TILED, POW2, X25>(fb, p.cube_res, X, Y, Z, cur);
+                    else if (face0 >= 2) count = taps_one_face<1, TILED, POW2, X25>(fb, p.cube_res, X, Y, Z, cur);
+                    else count = taps_one_face<0, TILED, POW2, X25>(fb, p.cube_res, X, Y, Z, cur);
+                }
             } else {  // the wave straddles a cube edge or corner
                 const unsigned axes = wave_major_axes(Fv.x, Fv.y, Fv.z, disk);
                 count = taps_any_face<TILED, POW2, X25>(cube, p.cube_res, X, Y, Z, cur, axes & 1u, axes & 2u, axes & 4u);
@@ -662,6 +722,140 @@ extern "C" int32_t vkr_tile_depth_cubes(const float *linear, float *tiled, int32
     return vkr_relayout_depth_cubes(linear, tiled, n_faces, res, VKR_CUBE_LAYOUT_TILED_8X4, stream);
 }
 
+namespace vkr {
+
+// Depth ranges, step 1: the smallest and largest comparison value of every RANGE_CELL x RANGE_CELL cell of every face.
+// Sixteen lanes take a cell (a wave four cells side by side, four times), each lane sixteen texels of a cell in four
+// 16-byte loads: in the tiled layouts a cell is two runs of 512 contiguous bytes (four 8x4 tiles of one tile column
+// each), in the row-major one sixteen 64-byte row segments.  FAST needs a face size that is a multiple of RANGE_CELL;
+// the other form reads texel by texel.  Cells are written to the slab behind the last level.
+static constexpr unsigned RANGE_CELLS_PER_WAVE = 16;
+template <int LAYOUT, bool FAST>
+__global__ __launch_bounds__(256) void cube_range_cells_kernel(const float *cubes, float2 *ranges, int res, unsigned cells, unsigned total_cells)
+{
+    const unsigned lane = threadIdx.x & 63u, q = lane & 15u;
+    const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    float lo[4], hi[4];
+    bool nan[4] = {false, false, false, false};
+    unsigned cell[4];
+#pragma unroll
+    for (unsigned it = 0; it < 4; it++) {
+        cell[it] = wave * RANGE_CELLS_PER_WAVE + it * 4u + (lane >> 4);  // over all faces: (face_all * cells + cy) * cells + cx
+        lo[it] = __builtin_inff(); hi[it] = -__builtin_inff();
+        if (cell[it] >= total_cells) continue;
+        const unsigned cx = cell[it] % cells, cy = (cell[it] / cells) % cells, face_all = cell[it] / (cells * cells);
+        const float *face = cubes + (size_t)face_all * res * res;
+        auto take = [&](float stored) {
+            const float closest = LAYOUT == VKR_CUBE_LAYOUT_TILED_8X4_X25 ? stored : stored * 25.0f;
+            nan[it] |= closest != closest;
+            lo[it] = __builtin_fminf(lo[it], closest); hi[it] = __builtin_fmaxf(hi[it], closest);
+        };
+#pragma unroll
+        for (unsigned r = 0; r < 4; r++) {
+            if (FAST) {
+                size_t at;  // in floats
+                if (LAYOUT == VKR_CUBE_LAYOUT_LINEAR) at = (size_t)(cy * RANGE_CELL + (q >> 2) + 4u * r) * res + cx * RANGE_CELL + (q & 3u) * 4u;
+                else at = (size_t)(cx * 2u + (r >> 1)) * 8u * res + (size_t)cy * (RANGE_CELL * 8u) + ((r & 1u) * 16u + q) * 4u;
+                typedef float float4_t __attribute__((ext_vector_type(4)));
+                const float4_t v = __builtin_nontemporal_load((const float4_t *)(face + at));  // read once: no reason to keep it in a cache
+                take(v.x); take(v.y); take(v.z); take(v.w);
+            } else {
+                const unsigned i = cx * RANGE_CELL + q;
+#pragma unroll
+                for (unsigned t = 0; t < 4; t++) {
+                    const unsigned j = cy * RANGE_CELL + r * 4u + t;
+                    if (i < (unsigned)res && j < (unsigned)res)
+                        take(face[LAYOUT == VKR_CUBE_LAYOUT_LINEAR ? (size_t)j * res + i : (size_t)(i >> 3) * 8u * res + 8u * j + (i & 7u)]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (unsigned it = 0; it < 4; it++) {
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) {  // over the sixteen lanes of the cell
+            lo[it] = __builtin_fminf(lo[it], __shfl_xor(lo[it], d)); hi[it] = __builtin_fmaxf(hi[it], __shfl_xor(hi[it], d));
+        }
+        // fmin / fmax drop a NaN: the cell is poisoned when any of its sixteen lanes saw one
+        if ((__builtin_amdgcn_ballot_w64(nan[it]) >> (lane & 48u)) & 0xFFFFull) { lo[it] = -__builtin_inff(); hi[it] = __builtin_inff(); }
+    }
+#pragma unroll
+    for (unsigned it = 0; it < 4; it++)
+        if (q == 0 && cell[it] < total_cells) {
+            const unsigned per_face = cells * cells, face_all = cell[it] / per_face, light = face_all / 6u, f = face_all - light * 6u;
+            ranges[(((size_t)light * (RANGE_LEVELS + 1) + RANGE_LEVELS) * 6u + f) * per_face + (cell[it] - face_all * per_face)] = make_float2(lo[it], hi[it]);
+        }
+}
+
+// Step 2, once per level in rising order: block (bx, by) of level 0 is the four cells (bx..bx+1, by..by+1); block
+// (bx, by) of level k > 0 is the blocks (2bx, 2by), (2bx+2, 2by), (2bx, 2by+2), (2bx+2, 2by+2) of level k - 1, which
+// tile it exactly; parts beyond the face's edge drop out.  One thread per entry of the padded level slab; entries
+// past the last block of a row or column hold (-inf, +inf) and are never read.  A poisoned part is (-inf, +inf)
+// and poisons the block.
+__global__ __launch_bounds__(256) void cube_range_level_kernel(float2 *ranges, unsigned cells, unsigned n_faces, unsigned level)
+{
+    const unsigned per_face = cells * cells;
+    const size_t id = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (id >= (size_t)n_faces * per_face) return;
+    const unsigned at = (unsigned)(id % per_face), bx = at % cells, by = at / cells, face_all = (unsigned)(id / per_face);
+    const unsigned light = face_all / 6u, f = face_all - light * 6u;
+    float2 *of_light = ranges + (size_t)light * (RANGE_LEVELS + 1) * 6u * per_face;
+    const float2 *part = of_light + ((size_t)(level == 0 ? RANGE_LEVELS : level - 1u) * 6u + f) * per_face;
+    const unsigned blocks = (cells + (1u << level) - 1u) >> level;
+    const unsigned parts = level == 0 ? cells : (cells + (1u << (level - 1u)) - 1u) >> (level - 1u);  // per row of the finer level
+    const unsigned step = level == 0 ? 1u : 2u, x0 = level == 0 ? bx : 2u * bx, y0 = level == 0 ? by : 2u * by;
+    float lo = -__builtin_inff(), hi = __builtin_inff();
+    if (bx < blocks && by < blocks) {
+        lo = __builtin_inff(); hi = -__builtin_inff();
+#pragma unroll
+        for (unsigned dy = 0; dy < 2; dy++)
+#pragma unroll
+            for (unsigned dx = 0; dx < 2; dx++) {
+                const unsigned x = x0 + dx * step, y = y0 + dy * step;
+                if (x < parts && y < parts) {
+                    const float2 c = part[(size_t)y * cells + x];
+                    lo = __builtin_fminf(lo, c.x); hi = __builtin_fmaxf(hi, c.y);
+                }
+            }
+    }
+    of_light[((size_t)level * 6u + f) * per_face + at] = make_float2(lo, hi);
+}
+
+}  // namespace vkr
+
+extern "C" int64_t vkr_cube_shadow_ranges_bytes(int32_t n_lights, int32_t res)
+{
+    using namespace vkr;
+    if (n_lights < 0 || res <= 0 || res > 8192) return -1;
+    const int64_t cells = (res + RANGE_CELL - 1) / RANGE_CELL;
+    return (int64_t)n_lights * (RANGE_LEVELS + 1) * 6 * cells * cells * (int64_t)sizeof(float2);
+}
+
+extern "C" int32_t vkr_cube_shadow_ranges(const float *cubes, int32_t n_lights, int32_t res, int32_t layout, void *ranges, void *stream)
+{
+    using namespace vkr;
+    VKR_REQUIRE(n_lights >= 0 && res > 0 && res <= 8192, "vkr_cube_shadow_ranges: bad size (%d lights, faces of %d)", n_lights, res);
+    VKR_REQUIRE(layout >= VKR_CUBE_LAYOUT_LINEAR && layout <= VKR_CUBE_LAYOUT_TILED_8X4_X25, "vkr_cube_shadow_ranges: unknown cube shadow layout %d", layout);
+    VKR_REQUIRE(layout == VKR_CUBE_LAYOUT_LINEAR || res % 8 == 0, "vkr_cube_shadow_ranges: the tiled layout needs a face size that is a multiple of 8 (got %d)", res);
+    if (n_lights == 0) return VKR_OK;
+    VKR_REQUIRE(cubes && ranges, "vkr_cube_shadow_ranges: a buffer is null");
+    const unsigned cells = (unsigned)((res + RANGE_CELL - 1) / RANGE_CELL), n_faces = (unsigned)n_lights * 6u;
+    VKR_REQUIRE((uint64_t)n_faces * cells * cells < (1ull << 31), "vkr_cube_shadow_ranges: too many cells for one launch (%d lights, faces of %d)", n_lights, res);
+    const unsigned total_cells = n_faces * cells * cells;  // at most 65535 * 512^2 would overflow: bounded below
+    typedef void (*kernel_t)(const float *, float2 *, int, unsigned, unsigned);
+    static const kernel_t kernels[6] = {
+        cube_range_cells_kernel<VKR_CUBE_LAYOUT_LINEAR, false>, cube_range_cells_kernel<VKR_CUBE_LAYOUT_LINEAR, true>,
+        cube_range_cells_kernel<VKR_CUBE_LAYOUT_TILED_8X4, false>, cube_range_cells_kernel<VKR_CUBE_LAYOUT_TILED_8X4, true>,
+        cube_range_cells_kernel<VKR_CUBE_LAYOUT_TILED_8X4_X25, false>, cube_range_cells_kernel<VKR_CUBE_LAYOUT_TILED_8X4_X25, true>};
+    const bool fast = res % RANGE_CELL == 0 && ((uintptr_t)cubes & 15u) == 0;
+    const unsigned per_block = 4u * RANGE_CELLS_PER_WAVE;
+    hipLaunchKernelGGL(kernels[layout * 2 + (fast ? 1 : 0)], dim3((total_cells + per_block - 1u) / per_block), dim3(256), 0, as_stream(stream),
+                       cubes, (float2 *)ranges, res, cells, total_cells);
+    for (unsigned level = 0; level < (unsigned)RANGE_LEVELS; level++)
+        hipLaunchKernelGGL(cube_range_level_kernel, dim3((total_cells + 255u) / 256u), dim3(256), 0, as_stream(stream), (float2 *)ranges, cells, n_faces, level);
+    return launch_status("vkr_cube_shadow_ranges");
+}
+
 extern "C" int32_t vkr_shade(const VkrShadeArgs *a, void *stream)
 {
     using namespace vkr;
@@ -692,6 +886,8 @@ extern "C" int32_t vkr_shade(const VkrShadeArgs *a, void *stream)
     p.out_color = (uint2 *)a->out_color; p.out_threshold = (uint2 *)a->out_threshold;
     p.coverage = a->coverage_mode == VKR_COVERAGE_MESH ? (const unsigned long long *)a->coverage_masks : nullptr;
     p.coverage_flags = p.coverage ? a->coverage_flags : nullptr;
+    p.cube_ranges = a->n_lights > 0 ? (const float2 *)a->cube_ranges : nullptr;
+    p.range_cells = (unsigned)((a->cube_res + RANGE_CELL - 1) / RANGE_CELL);
     for (int i = 0; i < 3; i++) {
         p.cam[i] = a->scene.camera_position[i];
         p.dir_dir[i] = a->scene.dir_light_direction[i];

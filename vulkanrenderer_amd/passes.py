@@ -65,16 +65,21 @@ class DeviceFrame:
     cube_layout: int = _lib.CUBE_LAYOUT_LINEAR
     coverage: torch.Tensor | None = None  # masks from light_coverage(); None: every light covers every pixel
     coverage_flags: torch.Tensor | None = None  # per-light "covers every pixel" words of the same light_coverage() call
+    cube_ranges: torch.Tensor | None = None  # cube_shadow_ranges(cube_shadow, cube_layout), or None: every tap is read
 
     @staticmethod
-    def upload(f: FrameInputs, device, tiled: bool | None = None) -> "DeviceFrame":
+    def upload(f: FrameInputs, device, tiled: bool | None = None, ranges: bool = True) -> "DeviceFrame":
         """`tiled`: how the point-shadow cubes are stored -- None: the layout the shading kernel is fastest on
-        (8x4-texel tiles of 25 * depth) whenever the face size allows; True: 8x4-texel tiles; False: rows."""
+        (8x4-texel tiles of 25 * depth) whenever the face size allows; True: 8x4-texel tiles; False: rows.
+        `ranges`: also build the depth ranges of the cubes, with which the shading kernel settles most lights of most
+        pixels without reading their 20 taps (same image either way)."""
         d = DeviceFrame._upload_linear(f, device)
         layout = _cube_layout_for(tiled, d.cube_shadow.shape[-1])
         if layout != _lib.CUBE_LAYOUT_LINEAR and d.n_lights > 0:
             d.cube_shadow = tile_depth_cubes(d.cube_shadow, layout)
             d.cube_layout = layout
+        if ranges and d.n_lights > 0:
+            d.cube_ranges = cube_shadow_ranges(d.cube_shadow, d.cube_layout)
         return d
 
     @staticmethod
@@ -213,6 +218,21 @@ def tile_depth_cubes(linear: torch.Tensor, layout: int = _lib.CUBE_LAYOUT_TILED_
     return out
 
 
+def cube_shadow_ranges(cubes: torch.Tensor, layout: int, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Depth ranges of the point-shadow cubes [n_lights, 6, res, res] stored in `layout` (DeviceFrame.cube_ranges):
+    a uint8 tensor [n_lights, bytes per light] of vkr_cube_shadow_ranges_bytes() bytes.  Rebuild whenever the cubes change."""
+    lib = _lib.load()
+    n_lights, res = cubes.shape[0], cubes.shape[-1]
+    need = lib.vkr_cube_shadow_ranges_bytes(n_lights, res)
+    if need < 0:
+        raise ValueError(f"cube_shadow_ranges: bad size ({n_lights} lights, faces of {res})")
+    if out is None:
+        out = torch.empty((n_lights, need // max(n_lights, 1)), dtype=torch.uint8, device=cubes.device)  # one row per light
+    assert out.numel() * out.element_size() >= need
+    _lib.check(lib.vkr_cube_shadow_ranges(_ptr(cubes), n_lights, res, layout, _ptr(out), _stream()))
+    return out
+
+
 def _scene_struct(scene: np.ndarray) -> _lib.SceneInfo:
     assert scene.dtype == SCENE_DTYPE
     return _lib.SceneInfo.from_buffer_copy(scene.tobytes())
@@ -232,6 +252,7 @@ def shade(f: DeviceFrame, out_color: torch.Tensor, out_threshold: torch.Tensor) 
     a.coverage_flags = _ptr(f.coverage_flags) if f.coverage is not None else None
     a.dir_shadow, a.dir_res = _ptr(f.dir_shadow), f.dir_shadow.shape[-1]
     a.cube_shadow, a.cube_res, a.cube_layout = _ptr(f.cube_shadow), f.cube_shadow.shape[-1], f.cube_layout
+    a.cube_ranges = _ptr(f.cube_ranges)
     a.irradiance, a.irr_res = _ptr(f.irradiance), f.irradiance.shape[1]
     a.prefilter, a.pref_res = _ptr(f.prefilter), f.prefilter.shape[1]
     a.brdf_lut, a.lut_res = _ptr(f.brdf_lut), f.brdf_lut.shape[0]

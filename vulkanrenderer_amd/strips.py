@@ -90,7 +90,8 @@ class HipBackend:
         sd = [(d["positions"], d["triangles"], d["model"]) for d in draws]
         cubes, layout = P.point_shadow_maps(sd, frame.lights, frame.n_lights, shadow_res)
         dmap = P.dir_shadow_map(sd, frame.scene["light_space_matrix"], dir_res, self.device)
-        return dataclasses.replace(frame, albedo=ga, normal=gn, arm=gm, position=gp, cube_shadow=cubes, cube_layout=layout, dir_shadow=dmap)
+        return dataclasses.replace(frame, albedo=ga, normal=gn, arm=gm, position=gp, cube_shadow=cubes, cube_layout=layout, dir_shadow=dmap,
+                                   cube_ranges=P.cube_shadow_ranges(cubes, layout))
 
     def with_coverage(self, frame, volume_mesh, frame_rows, row0):
         """The strip's frame with light-volume masks attached; `volume_mesh` = (verts, triangles) device tensors."""
