@@ -159,7 +159,12 @@ typedef struct VkrShadeArgs {
                                                      pixel the masks are not read */
     const void *cube_ranges;                      /* depth ranges of cube_shadow written by vkr_cube_shadow_ranges(), or NULL:
                                                      same output either way, fewer shadow-map fetches with them */
+    void *workspace;                              /* with cube_ranges: device memory of vkr_shade_workspace_bytes() for the
+                                                     per-tile light classes (lights whose taps are settled for a whole 8x8
+                                                     tile are skipped or taken as lit before any per-pixel work), or NULL */
+    int64_t workspace_bytes;
 } VkrShadeArgs;
+VKR_EXPORT int64_t vkr_shade_workspace_bytes(int32_t width, int32_t rows, int32_t n_lights);
 VKR_EXPORT int32_t vkr_shade(const VkrShadeArgs *args, void *stream);
 
 /* Depth ranges of the cube shadow maps, an acceleration structure for vkr_shade with no counterpart in the reference

@@ -1,0 +1,58 @@
+"""Tile-level classification estimate: per (8x8 tile, light), from the tile's position bounding box, can one range prove
+that every pixel's 20 taps are all in shadow / all lit?  Sizing only (approximate arithmetic)."""
+import sys, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vulkanrenderer_amd import synth
+W, H, L, RES = 3840, 2160, 64, 1024
+f = synth.make_frame(1, W, H, L, RES, 64)
+lights, cubes = f.lights, f.cube_shadow * 25.0
+cam = np.asarray(f.scene["camera_position"], np.float32)
+pos = f.position.view(np.float16).astype(np.float32)[..., :3].reshape(H // 8, 8, W // 8, 8, 3)
+nrm = f.normal.view(np.float16).astype(np.float32)[..., :3].reshape(H // 8, 8, W // 8, 8, 3)
+shaded = (nrm != 0).any(-1)                       # [ty, 8, tx, 8]
+big = np.where(shaded[..., None], pos, np.inf); small = np.where(shaded[..., None], pos, -np.inf)
+pmin = big.min(axis=(1, 3)).reshape(-1, 3); pmax = small.max(axis=(1, 3)).reshape(-1, 3)
+any_shaded = shaded.any(axis=(1, 3)).reshape(-1)
+rng = np.random.default_rng(0)
+sel = rng.choice(np.flatnonzero(any_shaded), 20000, replace=False)
+pmin, pmax = pmin[sel], pmax[sel]
+vdmax = np.linalg.norm(np.maximum(np.abs(pmin - cam), np.abs(pmax - cam)), axis=1); disk = (1 + vdmax / 25) / 25
+# block ranges: level k, stride S=16<<k, block 2S
+lv = []
+for k in range(4):
+    S = 16 << k; nb = RES // S
+    cm = cubes.reshape(L, 6, nb, S, nb, S)
+    mn1 = cm.min(axis=(3, 5)); mx1 = cm.max(axis=(3, 5))
+    pad = lambda a, fill: np.pad(a, ((0, 0), (0, 0), (0, 1), (0, 1)), constant_values=fill)
+    a, b = pad(mn1, np.inf), pad(mx1, -np.inf)
+    lv.append((np.minimum.reduce([a[:, :, :-1, :-1], a[:, :, 1:, :-1], a[:, :, :-1, 1:], a[:, :, 1:, 1:]]),
+               np.maximum.reduce([b[:, :, :-1, :-1], b[:, :, 1:, :-1], b[:, :, :-1, 1:], b[:, :, 1:, 1:]])))
+n = len(sel); tot = n * L; skip = lit = 0
+for i in range(L):
+    lo3, hi3 = pmin - lights["position"][i], pmax - lights["position"][i]
+    amin = np.where((lo3 <= 0) & (hi3 >= 0), 0, np.minimum(np.abs(lo3), np.abs(hi3))); amax = np.maximum(np.abs(lo3), np.abs(hi3))
+    cur_min = np.sqrt((amin ** 2).sum(1)) - 0.15; cur_max = np.sqrt((amax ** 2).sum(1)) - 0.15
+    ax = amin.argmax(1); idx = np.arange(n)
+    Mmin = amin[idx, ax] - disk; Mmax = amax[idx, ax] + disk
+    others = np.stack([amax[idx, (ax + 1) % 3], amax[idx, (ax + 2) % 3]], 1).max(1) + disk
+    one = (Mmin * (1 - 2**-20) >= others) & (Mmin > 0)
+    neg = hi3[idx, ax] < 0; face = ax * 2 + neg
+    o1 = np.where(ax == 0, 2, 0); o2 = np.where(ax == 0, 1, np.where(ax == 1, 2, 1))
+    def win(o):
+        ulo, uhi = lo3[idx, o] - disk, hi3[idx, o] + disk
+        q = [ulo / Mmin, ulo / Mmax, uhi / Mmin, uhi / Mmax]
+        a = np.floor((np.minimum.reduce(q) * 0.5 + 0.5) * RES) - 2; b = np.floor((np.maximum.reduce(q) * 0.5 + 0.5) * RES) + 2
+        return np.clip(a, 0, RES - 1).astype(int), np.clip(b, 0, RES - 1).astype(int)
+    with np.errstate(all="ignore"):
+        i0, i1 = win(o1); j0, j1 = win(o2)
+    width = np.maximum(i1 - i0, j1 - j0)
+    level = np.array([int(w >> 4).bit_length() for w in width])
+    ok = one & (level < 4)
+    s_skip = np.zeros(n, bool); s_lit = np.zeros(n, bool)
+    for k in range(4):
+        m = ok & (level == k); S = 16 << k
+        lo = lv[k][0][i, face[m], j0[m] // S, i0[m] // S]; hi = lv[k][1][i, face[m], j0[m] // S, i0[m] // S]
+        s_skip[m] = cur_min[m] > hi; s_lit[m] = cur_max[m] <= lo
+    skip += s_skip.sum(); lit += s_lit.sum()
+print(f"tile-level: skip {skip / tot:.3f}  lit {lit / tot:.3f}  general {(tot - skip - lit) / tot:.3f}")

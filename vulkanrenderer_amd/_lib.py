@@ -66,7 +66,7 @@ class ShadeArgs(C.Structure):
                 ("prefilter", C.c_void_p), ("pref_res", C.c_int32),
                 ("brdf_lut", C.c_void_p), ("lut_res", C.c_int32),
                 ("out_color", C.c_void_p), ("out_threshold", C.c_void_p), ("coverage_flags", C.c_void_p),
-                ("cube_ranges", C.c_void_p)]
+                ("cube_ranges", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 
 
 class CoverageArgs(C.Structure):
@@ -159,6 +159,7 @@ PROTOTYPES = {
     "vkr_tile_depth_cubes": [_vp, _vp, C.c_int32, C.c_int32, _vp],
     "vkr_relayout_depth_cubes": [_vp, _vp, _i32, _i32, _i32, _vp],
     "vkr_cube_shadow_ranges_bytes": [_i32, _i32],
+    "vkr_shade_workspace_bytes": [_i32, _i32, _i32],
     "vkr_cube_shadow_ranges": [_vp, _i32, _i32, _i32, _vp, _vp],
     "vkr_light_coverage": [C.POINTER(CoverageArgs), _vp],
     "vkr_point_shadow_maps": [C.POINTER(PointShadowArgs), _vp],
@@ -233,7 +234,7 @@ _lib = None
 
 RETURNS_INT64 = {"vkr_gbuffer_workspace_bytes", "vkr_ibl_irradiance_by_region_workspace_bytes",
                  "vkr_ibl_irradiance_by_region_rows_workspace_bytes", "vkr_env_footprint_tiles_bytes",
-                 "vkr_cube_shadow_ranges_bytes"}
+                 "vkr_cube_shadow_ranges_bytes", "vkr_shade_workspace_bytes"}
 
 
 def load() -> C.CDLL:

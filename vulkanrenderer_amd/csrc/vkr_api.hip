@@ -31,6 +31,7 @@ struct Frame {
     float *cube_shadow = nullptr;
     void *cube_ranges = nullptr;  // depth ranges of cube_shadow (vkr_cube_shadow_ranges), rebuilt before a composition pass
     int ranges_lights = 0;        // how many lights' ranges are current; 0 after any change of the cubes
+    void *shade_workspace = nullptr;  // vkr_shade_workspace_bytes(width, height, max_lights): the per-tile light classes
     VkrLightInfo *lights = nullptr;
     int n_lights = 0;
     int coverage = VKR_COVERAGE_FULLSCREEN;
@@ -90,7 +91,7 @@ static void free_frame_sized(vkr_ctx *c)
 {
     for (Frame &f : c->frames) {
         for (void *&g : f.gbuf) { if (g) (void)hipFree(g); g = nullptr; }
-        void **imgs[] = {&f.background, &f.color, &f.threshold_padded, &f.bloom1, &f.bloom2, &f.ldr, (void **)&f.coverage_buf};
+        void **imgs[] = {&f.background, &f.color, &f.threshold_padded, &f.bloom1, &f.bloom2, &f.ldr, (void **)&f.coverage_buf, &f.shade_workspace};
         for (void **p : imgs) { if (*p) (void)hipFree(*p); *p = nullptr; }
         f.threshold = nullptr;
         f.has_background = false;
@@ -113,6 +114,7 @@ static int32_t alloc_frame_sized(vkr_ctx *c)
         const size_t tiles = (size_t)((c->cfg.width + 7) / 8) * ((c->cfg.height + 7) / 8);
         // the masks, then the per-light words of VkrCoverageArgs.light_flags (max_lights + 1, rounded up to whole masks)
         VKR_HIP_CHECK(hipMalloc((void **)&f.coverage_buf, ((size_t)c->cfg.max_lights * tiles + (size_t)c->cfg.max_lights / 2 + 1) * sizeof(uint64_t)));
+        VKR_HIP_CHECK(hipMalloc(&f.shade_workspace, (size_t)std::max<int64_t>(vkr_shade_workspace_bytes(c->cfg.width, c->cfg.height, c->cfg.max_lights), 16)));
     }
     return VKR_OK;
 }
@@ -225,6 +227,8 @@ static int32_t fill_shade_args(vkr_ctx *c, Frame &f, VkrShadeArgs &a)
     a.cube_shadow = f.cube_shadow; a.cube_res = c->cfg.point_shadow_res;
     a.cube_layout = c->cubes_tiled ? VKR_CUBE_LAYOUT_TILED_8X4_X25 : VKR_CUBE_LAYOUT_LINEAR;
     a.cube_ranges = f.n_lights > 0 ? f.cube_ranges : nullptr;  // brought up to date by shade() below
+    a.workspace = f.shade_workspace;
+    a.workspace_bytes = vkr_shade_workspace_bytes(c->cfg.width, c->cfg.height, c->cfg.max_lights);
     a.irradiance = c->irradiance; a.irr_res = c->cfg.irradiance_res;
     a.prefilter = c->prefilter[0]; a.pref_res = c->cfg.prefilter_res;
     a.brdf_lut = c->brdf_lut; a.lut_res = c->cfg.brdf_lut_res;

@@ -38,6 +38,8 @@ struct ShadeParams {
     const unsigned *coverage_flags;      // with masks: word n_lights = number of lights that do not cover every pixel; or null
     const float2 *cube_ranges;           // depth ranges of blocks of the cube maps (see cube_ranges_* below), or null
     unsigned range_cells;                // ceil(cube_res / RANGE_CELL)
+    const unsigned long long *light_classes;  // per (tile, 64 lights) two masks written by light_classes_kernel, or null
+    int class_words;                     // ceil(n_lights / 64)
     float cam[3];
     float dir_dir[3];
     float dir_color[3];
@@ -243,6 +245,13 @@ VKR_DEV float taps_one_face(const float *face_base, int res, const float (&X)[3]
 // Memory: [light][level][face][cells][cells] pairs of floats with cells = ceil(res / RANGE_CELL) at every level (rows
 // and slabs of the coarser levels are padded to the size of level 0, which keeps the address arithmetic uniform).
 static constexpr int RANGE_CELL = 16, RANGE_LEVELS = 4;
+
+#ifdef VKR_EXPERIMENT_COUNT  // kernel experiments only: what happens to each (wave, light) pair
+__device__ unsigned long long shade_counts[8];
+#define VKR_COUNT(i) do { if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) atomicAdd(&shade_counts[i], 1ull); } while (0)
+#else
+#define VKR_COUNT(i) do { } while (0)
+#endif
 
 // The one-face case again: are the 20 comparisons of this lane all true, or all false?  A tap's column is
 // floor(t) for t = (u / m) h + h evaluated in binary32 (h = res / 2), with u within r of the centre's u0 and |m| within
@@ -556,6 +565,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         typedef const __attribute__((address_space(4))) unsigned long long cmask;
         cmask *cover_c = (cmask *)p.coverage;
         const size_t tiles = (size_t)p.tiles_x * p.tiles_y, tile = (size_t)tile_y * p.tiles_x + tile_x;
+        cmask *classes_c = p.light_classes ? (cmask *)p.light_classes + tile * (size_t)(p.class_words * 2) : nullptr;
         // The light loop, with or without the per-light masks.  A kernel built for masks holds both forms: when the
         // coverage pass found that every light covers every pixel (the reference's own light radii, with the camera
         // inside every volume) its waves take the form without masks, which costs neither the mask loads nor the
@@ -563,6 +573,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         // in the instruction cache.
         auto light_loop = [&](auto use_masks) {
         constexpr bool MASKS = decltype(use_masks)::value;
+        unsigned long long skip_word = 0ull, lit_word = 0ull;  // classes of the 64 lights li belongs to, bit li & 63
         for (int li = p.light_begin; li < p.light_end; li++) {
             const f3 lp = lp_next, lc = lc_next;
             {
@@ -570,6 +581,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                 lp_next = mk3(lf[16], lf[17], lf[18]);
                 lc_next = mk3(lf[20], lf[21], lf[22]);
             }
+            if (classes_c) {
+                if (li == p.light_begin || (li & 63) == 0) {
+                    skip_word = classes_c[(li >> 6) * 2];
+                    lit_word = classes_c[(li >> 6) * 2 + 1];
+                }
+                if ((skip_word >> (li & 63)) & 1ull) continue;  // every pixel of the tile has all 20 taps in shadow: adds exactly zero
+            }
+            const bool tile_lit = (lit_word >> (li & 63)) & 1ull;  // no tap of any pixel of the tile is in shadow
             bool covered = true;
             unsigned long long cover_mask = ~0ull;
             if (MASKS) {
@@ -606,10 +625,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             // faces away from the light is done.  Masks of single comparisons are combined as scalars.
             unsigned long long live = __builtin_amdgcn_ballot_w64(slow_domain) | __builtin_amdgcn_ballot_w64(NdotL > 0.0f);
             if (MASKS) live &= cover_mask;
-            if (live == 0ull) continue;
-            const int face0 = wave_common_face(Fv.x, Fv.y, Fv.z, disk);
+            if (live == 0ull) { VKR_COUNT(0); continue; }
+            const int face0 = tile_lit ? -2 : wave_common_face(Fv.x, Fv.y, Fv.z, disk);
             float count;
-            if (face0 >= 0) {
+            if (tile_lit) {
+                count = 0.0f;
+            } else if (face0 >= 0) {
                 bool settled = false;
                 if (p.cube_ranges) {  // one fetch of a depth range may stand for the 20 taps, for every lane that matters
                     const float2 *fr = p.cube_ranges + ((size_t)li * ((RANGE_LEVELS + 1) * 6) + face0) * p.range_cells * p.range_cells;
@@ -618,6 +639,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                     else if (face0 >= 2) lane_settled = taps_settled_by_ranges<1, POW2>(fr, p.range_cells, p.cube_res, Fv.x, Fv.y, Fv.z, disk, range_hr, cur, count);
                     else lane_settled = taps_settled_by_ranges<0, POW2>(fr, p.range_cells, p.cube_res, Fv.x, Fv.y, Fv.z, disk, range_hr, cur, count);
                     settled = (live & ~__builtin_amdgcn_ballot_w64(lane_settled)) == 0ull;
+                    if (settled) VKR_COUNT(1); else VKR_COUNT(2);
                 }
                 if (!settled) {
                     const float *fb = cube + (size_t)face0 * face_stride;
@@ -626,11 +648,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                     else count = taps_one_face<0, TILED, POW2, X25>(fb, p.cube_res, X, Y, Z, cur);
                 }
             } else {  // the wave straddles a cube edge or corner
+                VKR_COUNT(3);
                 const unsigned axes = wave_major_axes(Fv.x, Fv.y, Fv.z, disk);
                 count = taps_any_face<TILED, POW2, X25>(cube, p.cube_res, X, Y, Z, cur, axes & 1u, axes & 2u, axes & 4u);
             }
             // all 20 taps in shadow: the factor 1 - 20/20 is an exact zero, same argument
-            if ((live & (__builtin_amdgcn_ballot_w64(slow_domain) | __builtin_amdgcn_ballot_w64(count < 20.0f))) == 0ull) continue;
+            if ((live & (__builtin_amdgcn_ballot_w64(slow_domain) | __builtin_amdgcn_ballot_w64(count < 20.0f))) == 0ull) { VKR_COUNT(4); continue; }
+            VKR_COUNT(5);
             const f3 Hv = add3(V, L);
             const float hlen2 = dot3(Hv, Hv);  // at most about 4: only the lower end of the fast domain needs a test
             float inv_hlen;
@@ -821,7 +845,141 @@ __global__ __launch_bounds__(256) void cube_range_level_kernel(float2 *ranges, u
     of_light[((size_t)level * 6u + f) * per_face + at] = make_float2(lo, hi);
 }
 
+// What the depth ranges say about a whole 8x8-pixel tile and a light, decided once per pair instead of once per pixel:
+// bit l of the first mask = every tap of every pixel of the tile that takes part in the light loop is in shadow for
+// light l (the light adds exactly zero and the shading kernel skips it before computing anything), bit l of the second
+// = none is (the kernel takes count 0 without looking).  One wave per tile.  Its lanes first read the tile's pixels
+// and reduce the bounding box of their positions and their largest disk radius; then lane l bounds, for light l,
+// what the shading kernel computes per pixel, using that every step is a correctly rounded, monotone operation:
+//   fragToLight = RN(pos - lp) lies between the values at the box's ends, component by component; its squared
+//   length (dot3: a product and two fmas of non-negative terms) between dot3 of the smallest and of the largest
+//   magnitudes, so cur = RN(RN(sqrt) - 0.15) between cur_min and cur_max computed by the same operations;
+//   a tap coordinate RN(f +- disk) between RN(f_lo - disk_max) and RN(f_hi + disk_max);
+//   when the smallest magnitude of one coordinate's candidates exceeds the largest of both others, every tap of
+//   every pixel selects that face (ties cannot occur) and the sign of the major coordinate is fixed;
+//   a face coordinate is then +-u / |m| with u and |m| in known intervals: its extremes lie at the intervals' ends.
+//   Texel indices are floors of values below 2^13 evaluated with relative errors of a few 2^-24 here and in the
+//   shading kernel, so both floors are within 1 of the exact one: the window is widened by 2 texels on every side.
+// A window narrower than S = 16 << level lies inside one block of that level (see taps_settled_by_ranges); its range
+// against cur_min / cur_max decides.  Tiles with a non-finite position or disk radius among their pixels, distances
+// outside the range where the kernel's own skip is valid (2^-96 <= |fragToLight|^2 <= 2^96), or windows too wide,
+// get neither bit, and the shading kernel decides per pixel as before.
+__global__ __launch_bounds__(64) void light_classes_kernel(const ShadeParams p, unsigned long long *classes)
+{
+    const unsigned tile = blockIdx.x;
+    const int tile_x = (int)(tile % (unsigned)p.tiles_x), tile_y = (int)(tile / (unsigned)p.tiles_x);
+    const int lane = threadIdx.x;
+    const int x = tile_x * 8 + (lane & 7), y = tile_y * 8 + (lane >> 3);
+    const float inf = __builtin_inff();
+    float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf}, disk_max = 0.0f;
+    bool takes_part = false, bad = false;
+    if (x < p.width && y < p.rows) {
+        const size_t px = (size_t)y * p.width + x;
+        const rgba no = unpack4(p.normal[px]);
+        const f3 nraw = mk3(no.r, no.g, no.b);
+        takes_part = dot3(nraw, nraw) > 0.0f;  // the shading kernel's own test
+        if (takes_part) {
+            const rgba po = unpack4(p.position[px]);
+            const f3 pos = mk3(po.r, po.g, po.b);
+            const f3 Vraw = sub3(mk3(p.cam[0], p.cam[1], p.cam[2]), pos);
+            const float view_distance = sqrt_rn(dot3(Vraw, Vraw));
+            const float disk = fma_(view_distance, 1.0f / 25.0f, 1.0f) * (1.0f / 25.0f);
+            bad = !(__builtin_fabsf(pos.x) < inf && __builtin_fabsf(pos.y) < inf && __builtin_fabsf(pos.z) < inf && disk < inf);
+            lo[0] = hi[0] = pos.x; lo[1] = hi[1] = pos.y; lo[2] = hi[2] = pos.z;
+            disk_max = disk;
+        }
+    }
+    const bool usable = __builtin_amdgcn_ballot_w64(takes_part) != 0ull && __builtin_amdgcn_ballot_w64(bad) == 0ull;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            lo[c] = __builtin_fminf(lo[c], __shfl_xor(lo[c], d));
+            hi[c] = __builtin_fmaxf(hi[c], __shfl_xor(hi[c], d));
+        }
+        disk_max = __builtin_fmaxf(disk_max, __shfl_xor(disk_max, d));
+    }
+    const float fres = (float)p.cube_res, half = 0.5f * fres;
+    for (int word = 0; word < p.class_words; word++) {
+        const int li = word * 64 + lane;
+        bool skip = false, lit = false;
+        if (usable && li < p.n_lights) {
+            const float *lf = p.lights + (size_t)li * 23;
+            const float lp[3] = {lf[16], lf[17], lf[18]};
+            float f_lo[3], f_hi[3], a_min[3], a_max[3], c_lo[3], c_hi[3], c_min[3], c_max[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                f_lo[c] = lo[c] - lp[c]; f_hi[c] = hi[c] - lp[c];
+                a_max[c] = __builtin_fmaxf(__builtin_fabsf(f_lo[c]), __builtin_fabsf(f_hi[c]));
+                a_min[c] = (f_lo[c] <= 0.0f && f_hi[c] >= 0.0f) ? 0.0f : __builtin_fminf(__builtin_fabsf(f_lo[c]), __builtin_fabsf(f_hi[c]));
+                c_lo[c] = f_lo[c] - disk_max; c_hi[c] = f_hi[c] + disk_max;
+                c_max[c] = __builtin_fmaxf(__builtin_fabsf(c_lo[c]), __builtin_fabsf(c_hi[c]));
+                c_min[c] = (c_lo[c] <= 0.0f && c_hi[c] >= 0.0f) ? 0.0f : __builtin_fminf(__builtin_fabsf(c_lo[c]), __builtin_fabsf(c_hi[c]));
+            }
+            const float d2_min = dot3(mk3(a_min[0], a_min[1], a_min[2]), mk3(a_min[0], a_min[1], a_min[2]));
+            const float d2_max = dot3(mk3(a_max[0], a_max[1], a_max[2]), mk3(a_max[0], a_max[1], a_max[2]));
+            const bool in_domain = d2_min >= 0x1p-96f && d2_max <= 0x1p96f;  // false for NaN
+            const float cur_min = sqrt_rn(d2_min) - 0.15f, cur_max = sqrt_rn(d2_max) - 0.15f;
+            const int m = (c_min[2] >= c_min[1] && c_min[2] >= c_min[0]) ? 2 : (c_min[1] >= c_min[0] ? 1 : 0);
+            const int o1 = m == 0 ? 1 : 0, o2 = m == 2 ? 1 : 2;
+            float m_min = c_min[0], m_max = c_max[0], m_hi = c_hi[0];
+            if (m == 1) { m_min = c_min[1]; m_max = c_max[1]; m_hi = c_hi[1]; }
+            if (m == 2) { m_min = c_min[2]; m_max = c_max[2]; m_hi = c_hi[2]; }
+            const float other = __builtin_fmaxf(m == 0 ? c_max[1] : c_max[0], m == 2 ? c_max[1] : c_max[2]);
+            (void)o1; (void)o2;
+            const bool one_face = m_min > other && m_max < 0x1p100f;
+            if (in_domain && one_face) {
+                const bool negative = m_hi < 0.0f;
+                const int face = m * 2 + (negative ? 1 : 0);
+                // sc and tc: which coordinate, and the sign it is taken with (taps_one_face)
+                int su_axis, sw_axis; float su_sign, sw_sign;
+                const float sgn = negative ? -1.0f : 1.0f;
+                if (m == 2) { su_axis = 0; su_sign = sgn; sw_axis = 1; sw_sign = -1.0f; }
+                else if (m == 1) { su_axis = 0; su_sign = 1.0f; sw_axis = 2; sw_sign = sgn; }
+                else { su_axis = 2; su_sign = -sgn; sw_axis = 1; sw_sign = -1.0f; }
+                const float r_small = 1.0f / m_max, r_large = 1.0f / m_min;
+                auto window = [&](int axis, float sign, int &first, int &last) {
+                    float u_lo = axis == 0 ? c_lo[0] : (axis == 1 ? c_lo[1] : c_lo[2]);
+                    float u_hi = axis == 0 ? c_hi[0] : (axis == 1 ? c_hi[1] : c_hi[2]);
+                    if (sign < 0.0f) { const float t = u_lo; u_lo = -u_hi; u_hi = -t; }
+                    const float q_lo = __builtin_fminf(u_lo * r_small, u_lo * r_large), q_hi = __builtin_fmaxf(u_hi * r_small, u_hi * r_large);
+                    const float t_lo = fma_(q_lo, half, half), t_hi = fma_(q_hi, half, half);  // within (0, res): |u| < |m|
+                    first = max((int)__builtin_floorf(t_lo) - 2, 0);
+                    last = min((int)__builtin_floorf(t_hi) + 2, p.cube_res - 1);
+                };
+                int i0, i1, j0, j1;
+                window(su_axis, su_sign, i0, i1);
+                window(sw_axis, sw_sign, j0, j1);
+                const unsigned width = (unsigned)max(max(i1 - i0, j1 - j0), 0);
+                const unsigned level = 32u - (unsigned)__clz((int)(width >> 4));  // smallest k with width < 16 << k
+                if (level < (unsigned)RANGE_LEVELS) {
+                    const unsigned shift = 4u + level;
+                    const size_t per_face = (size_t)p.range_cells * p.range_cells;
+                    const float2 range = p.cube_ranges[(((size_t)li * (RANGE_LEVELS + 1) + level) * 6u + (unsigned)face) * per_face +
+                                                       (size_t)((unsigned)j0 >> shift) * p.range_cells + ((unsigned)i0 >> shift)];
+                    skip = cur_min > range.y;
+                    lit = !(cur_max > range.x);
+                }
+            }
+        }
+        const unsigned long long skip_mask = __builtin_amdgcn_ballot_w64(skip), lit_mask = __builtin_amdgcn_ballot_w64(lit);
+        if (lane == 0) {
+            classes[((size_t)tile * p.class_words + word) * 2] = skip_mask;
+            classes[((size_t)tile * p.class_words + word) * 2 + 1] = lit_mask;
+        }
+    }
+}
+
 }  // namespace vkr
+
+#ifdef VKR_EXPERIMENT_COUNT
+extern "C" __attribute__((visibility("default"))) int32_t vkr_experiment_shade_counts(unsigned long long *out8, int32_t reset)
+{
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(vkr::shade_counts), 64) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(vkr::shade_counts), z, 64) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 
 extern "C" int64_t vkr_cube_shadow_ranges_bytes(int32_t n_lights, int32_t res)
 {
@@ -856,6 +1014,13 @@ extern "C" int32_t vkr_cube_shadow_ranges(const float *cubes, int32_t n_lights, 
     return launch_status("vkr_cube_shadow_ranges");
 }
 
+extern "C" int64_t vkr_shade_workspace_bytes(int32_t width, int32_t rows, int32_t n_lights)
+{
+    if (width <= 0 || rows <= 0 || n_lights < 0) return -1;
+    const int64_t tiles = (int64_t)((width + 7) / 8) * ((rows + 7) / 8), words = (n_lights + 63) / 64;
+    return tiles * words * 2 * (int64_t)sizeof(unsigned long long);
+}
+
 extern "C" int32_t vkr_shade(const VkrShadeArgs *a, void *stream)
 {
     using namespace vkr;
@@ -888,6 +1053,14 @@ extern "C" int32_t vkr_shade(const VkrShadeArgs *a, void *stream)
     p.coverage_flags = p.coverage ? a->coverage_flags : nullptr;
     p.cube_ranges = a->n_lights > 0 ? (const float2 *)a->cube_ranges : nullptr;
     p.range_cells = (unsigned)((a->cube_res + RANGE_CELL - 1) / RANGE_CELL);
+    p.class_words = (a->n_lights + 63) / 64;
+    p.light_classes = nullptr;
+    if (p.cube_ranges && a->workspace) {
+        VKR_REQUIRE(a->workspace_bytes >= vkr_shade_workspace_bytes(a->width, a->rows, a->n_lights),
+                    "vkr_shade: workspace of %lld bytes, vkr_shade_workspace_bytes() asks for %lld", (long long)a->workspace_bytes,
+                    (long long)vkr_shade_workspace_bytes(a->width, a->rows, a->n_lights));
+        p.light_classes = (const unsigned long long *)a->workspace;
+    }
     for (int i = 0; i < 3; i++) {
         p.cam[i] = a->scene.camera_position[i];
         p.dir_dir[i] = a->scene.dir_light_direction[i];
@@ -917,6 +1090,8 @@ extern "C" int32_t vkr_shade(const VkrShadeArgs *a, void *stream)
 #else
     const int chunk = SHADE_LIGHTS_PER_LAUNCH;
 #endif
+    if (p.light_classes)
+        hipLaunchKernelGGL(light_classes_kernel, dim3((unsigned)(p.tiles_x * p.tiles_y)), dim3(64), 0, as_stream(stream), p, (unsigned long long *)a->workspace);
     p.light_begin = 0;
     do {
         p.light_end = a->n_lights - p.light_begin <= chunk + chunk / 2 ? a->n_lights : p.light_begin + chunk;  // no short tail launch

@@ -66,6 +66,7 @@ class DeviceFrame:
     coverage: torch.Tensor | None = None  # masks from light_coverage(); None: every light covers every pixel
     coverage_flags: torch.Tensor | None = None  # per-light "covers every pixel" words of the same light_coverage() call
     cube_ranges: torch.Tensor | None = None  # cube_shadow_ranges(cube_shadow, cube_layout), or None: every tap is read
+    shade_workspace: torch.Tensor | None = None  # made by shade() on first use: the per-tile light classes
 
     @staticmethod
     def upload(f: FrameInputs, device, tiled: bool | None = None, ranges: bool = True) -> "DeviceFrame":
@@ -253,6 +254,11 @@ def shade(f: DeviceFrame, out_color: torch.Tensor, out_threshold: torch.Tensor) 
     a.dir_shadow, a.dir_res = _ptr(f.dir_shadow), f.dir_shadow.shape[-1]
     a.cube_shadow, a.cube_res, a.cube_layout = _ptr(f.cube_shadow), f.cube_shadow.shape[-1], f.cube_layout
     a.cube_ranges = _ptr(f.cube_ranges)
+    if f.cube_ranges is not None and f.n_lights > 0:
+        need = lib.vkr_shade_workspace_bytes(f.width, f.rows, f.n_lights)
+        if f.shade_workspace is None or f.shade_workspace.numel() < need:
+            f.shade_workspace = torch.empty(need, dtype=torch.uint8, device=f.albedo.device)
+        a.workspace, a.workspace_bytes = _ptr(f.shade_workspace), f.shade_workspace.numel()
     a.irradiance, a.irr_res = _ptr(f.irradiance), f.irradiance.shape[1]
     a.prefilter, a.pref_res = _ptr(f.prefilter), f.prefilter.shape[1]
     a.brdf_lut, a.lut_res = _ptr(f.brdf_lut), f.brdf_lut.shape[0]
