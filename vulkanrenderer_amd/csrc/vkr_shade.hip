@@ -845,6 +845,24 @@ __global__ __launch_bounds__(256) void cube_range_level_kernel(float2 *ranges, u
     of_light[((size_t)level * 6u + f) * per_face + at] = make_float2(lo, hi);
 }
 
+// The largest value over the 64 lanes of the wave (every lane active, no NaN), as a wave-uniform value, without going
+// through LDS: four data-parallel-primitive steps leave each row of 16 lanes holding its row's maximum (swap with the
+// neighbour, with the other pair of the quad, with the mirrored half row, with the mirrored row), two broadcast steps
+// carry the maxima across the rows into the last one, and lane 63 is read as a scalar.  Written as instructions: the
+// compiler's form of a max is preceded by a canonicalising max of its own and a DPP move, three times the count.
+// (A DPP operand written by the instruction before needs two wait states, which inline code has to provide itself.)
+VKR_DEV float wave_max_uniform(float v)
+{
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1" : "+v"(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // What the depth ranges say about a whole 8x8-pixel tile and a light, decided once per pair instead of once per pixel:
 // bit l of the first mask = every tap of every pixel of the tile that takes part in the light loop is in shadow for
 // light l (the light adds exactly zero and the shading kernel skips it before computing anything), bit l of the second
@@ -864,25 +882,29 @@ __global__ __launch_bounds__(256) void cube_range_level_kernel(float2 *ranges, u
 // against cur_min / cur_max decides.  Tiles with a non-finite position or disk radius among their pixels, distances
 // outside the range where the kernel's own skip is valid (2^-96 <= |fragToLight|^2 <= 2^96), or windows too wide,
 // get neither bit, and the shading kernel decides per pixel as before.
-__global__ __launch_bounds__(64) void light_classes_kernel(const ShadeParams p, unsigned long long *classes)
+__global__ __launch_bounds__(256) void light_classes_kernel(const ShadeParams p, unsigned long long *classes)
 {
-    const unsigned tile = blockIdx.x;
+    const unsigned tile = blockIdx.x * 4u + (threadIdx.x >> 6);  // four waves, a tile each
+    if (tile >= (unsigned)(p.tiles_x * p.tiles_y)) return;       // a whole wave: the cross-lane steps below see 64 lanes or none
     const int tile_x = (int)(tile % (unsigned)p.tiles_x), tile_y = (int)(tile / (unsigned)p.tiles_x);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int x = tile_x * 8 + (lane & 7), y = tile_y * 8 + (lane >> 3);
     const float inf = __builtin_inff();
     float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf}, disk_max = 0.0f;
     bool takes_part = false, bad = false;
     if (x < p.width && y < p.rows) {
         const size_t px = (size_t)y * p.width + x;
-        const rgba no = unpack4(p.normal[px]);
+        const uint2 normal_bits = p.normal[px], position_bits = p.position[px];  // both loads in flight together
+        const rgba no = unpack4(normal_bits);
         const f3 nraw = mk3(no.r, no.g, no.b);
         takes_part = dot3(nraw, nraw) > 0.0f;  // the shading kernel's own test
         if (takes_part) {
-            const rgba po = unpack4(p.position[px]);
+            const rgba po = unpack4(position_bits);
             const f3 pos = mk3(po.r, po.g, po.b);
             const f3 Vraw = sub3(mk3(p.cam[0], p.cam[1], p.cam[2]), pos);
-            const float view_distance = sqrt_rn(dot3(Vraw, Vraw));
+            // an upper bound of the pixel's disk radius is all that is needed: the hardware root, one unit in the
+            // last place off at most, with a margin, through the kernel's own (monotone) fma and product
+            const float view_distance = __builtin_amdgcn_sqrtf(dot3(Vraw, Vraw)) * (1.0f + 0x1p-20f);
             const float disk = fma_(view_distance, 1.0f / 25.0f, 1.0f) * (1.0f / 25.0f);
             bad = !(__builtin_fabsf(pos.x) < inf && __builtin_fabsf(pos.y) < inf && __builtin_fabsf(pos.z) < inf && disk < inf);
             lo[0] = hi[0] = pos.x; lo[1] = hi[1] = pos.y; lo[2] = hi[2] = pos.z;
@@ -891,14 +913,8 @@ __global__ __launch_bounds__(64) void light_classes_kernel(const ShadeParams p, 
     }
     const bool usable = __builtin_amdgcn_ballot_w64(takes_part) != 0ull && __builtin_amdgcn_ballot_w64(bad) == 0ull;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            lo[c] = __builtin_fminf(lo[c], __shfl_xor(lo[c], d));
-            hi[c] = __builtin_fmaxf(hi[c], __shfl_xor(hi[c], d));
-        }
-        disk_max = __builtin_fmaxf(disk_max, __shfl_xor(disk_max, d));
-    }
+    for (int c = 0; c < 3; c++) { lo[c] = -wave_max_uniform(-lo[c]); hi[c] = wave_max_uniform(hi[c]); }
+    disk_max = wave_max_uniform(disk_max);
     const float fres = (float)p.cube_res, half = 0.5f * fres;
     for (int word = 0; word < p.class_words; word++) {
         const int li = word * 64 + lane;
@@ -906,28 +922,29 @@ __global__ __launch_bounds__(64) void light_classes_kernel(const ShadeParams p, 
         if (usable && li < p.n_lights) {
             const float *lf = p.lights + (size_t)li * 23;
             const float lp[3] = {lf[16], lf[17], lf[18]};
+            // an interval [a, b] with a <= b: its smallest magnitude is max(a, -b, 0), its largest max(-a, b)
             float f_lo[3], f_hi[3], a_min[3], a_max[3], c_lo[3], c_hi[3], c_min[3], c_max[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 f_lo[c] = lo[c] - lp[c]; f_hi[c] = hi[c] - lp[c];
-                a_max[c] = __builtin_fmaxf(__builtin_fabsf(f_lo[c]), __builtin_fabsf(f_hi[c]));
-                a_min[c] = (f_lo[c] <= 0.0f && f_hi[c] >= 0.0f) ? 0.0f : __builtin_fminf(__builtin_fabsf(f_lo[c]), __builtin_fabsf(f_hi[c]));
+                a_max[c] = __builtin_fmaxf(-f_lo[c], f_hi[c]);
+                a_min[c] = __builtin_fmaxf(__builtin_fmaxf(f_lo[c], -f_hi[c]), 0.0f);
                 c_lo[c] = f_lo[c] - disk_max; c_hi[c] = f_hi[c] + disk_max;
-                c_max[c] = __builtin_fmaxf(__builtin_fabsf(c_lo[c]), __builtin_fabsf(c_hi[c]));
-                c_min[c] = (c_lo[c] <= 0.0f && c_hi[c] >= 0.0f) ? 0.0f : __builtin_fminf(__builtin_fabsf(c_lo[c]), __builtin_fabsf(c_hi[c]));
+                c_max[c] = __builtin_fmaxf(-c_lo[c], c_hi[c]);
+                c_min[c] = __builtin_fmaxf(__builtin_fmaxf(c_lo[c], -c_hi[c]), 0.0f);
             }
             const float d2_min = dot3(mk3(a_min[0], a_min[1], a_min[2]), mk3(a_min[0], a_min[1], a_min[2]));
             const float d2_max = dot3(mk3(a_max[0], a_max[1], a_max[2]), mk3(a_max[0], a_max[1], a_max[2]));
             const bool in_domain = d2_min >= 0x1p-96f && d2_max <= 0x1p96f;  // false for NaN
-            const float cur_min = sqrt_rn(d2_min) - 0.15f, cur_max = sqrt_rn(d2_max) - 0.15f;
-            const int m = (c_min[2] >= c_min[1] && c_min[2] >= c_min[0]) ? 2 : (c_min[1] >= c_min[0] ? 1 : 0);
-            const int o1 = m == 0 ? 1 : 0, o2 = m == 2 ? 1 : 2;
-            float m_min = c_min[0], m_max = c_max[0], m_hi = c_hi[0];
-            if (m == 1) { m_min = c_min[1]; m_max = c_max[1]; m_hi = c_hi[1]; }
-            if (m == 2) { m_min = c_min[2]; m_max = c_max[2]; m_hi = c_hi[2]; }
-            const float other = __builtin_fmaxf(m == 0 ? c_max[1] : c_max[0], m == 2 ? c_max[1] : c_max[2]);
-            (void)o1; (void)o2;
-            const bool one_face = m_min > other && m_max < 0x1p100f;
+            // both roots are correctly rounded inside the domain just tested, and unused outside it
+            const float cur_min = fast_sqrt_rn(d2_min) - 0.15f, cur_max = fast_sqrt_rn(d2_max) - 0.15f;
+            // at most one coordinate can exceed both others over all candidates
+            const bool z_major = c_min[2] > __builtin_fmaxf(c_max[0], c_max[1]), y_major = c_min[1] > __builtin_fmaxf(c_max[0], c_max[2]);
+            const bool x_major = c_min[0] > __builtin_fmaxf(c_max[1], c_max[2]);
+            const int m = z_major ? 2 : (y_major ? 1 : 0);
+            const float m_min = z_major ? c_min[2] : (y_major ? c_min[1] : c_min[0]), m_max = z_major ? c_max[2] : (y_major ? c_max[1] : c_max[0]);
+            const float m_hi = z_major ? c_hi[2] : (y_major ? c_hi[1] : c_hi[0]);
+            const bool one_face = (z_major || y_major || x_major) && m_max < 0x1p100f;
             if (in_domain && one_face) {
                 const bool negative = m_hi < 0.0f;
                 const int face = m * 2 + (negative ? 1 : 0);
@@ -937,7 +954,7 @@ __global__ __launch_bounds__(64) void light_classes_kernel(const ShadeParams p, 
                 if (m == 2) { su_axis = 0; su_sign = sgn; sw_axis = 1; sw_sign = -1.0f; }
                 else if (m == 1) { su_axis = 0; su_sign = 1.0f; sw_axis = 2; sw_sign = sgn; }
                 else { su_axis = 2; su_sign = -sgn; sw_axis = 1; sw_sign = -1.0f; }
-                const float r_small = 1.0f / m_max, r_large = 1.0f / m_min;
+                const float r_small = __builtin_amdgcn_rcpf(m_max), r_large = __builtin_amdgcn_rcpf(m_min);  // one unit in the last place off at most
                 auto window = [&](int axis, float sign, int &first, int &last) {
                     float u_lo = axis == 0 ? c_lo[0] : (axis == 1 ? c_lo[1] : c_lo[2]);
                     float u_hi = axis == 0 ? c_hi[0] : (axis == 1 ? c_hi[1] : c_hi[2]);
@@ -1091,7 +1108,7 @@ extern "C" int32_t vkr_shade(const VkrShadeArgs *a, void *stream)
     const int chunk = SHADE_LIGHTS_PER_LAUNCH;
 #endif
     if (p.light_classes)
-        hipLaunchKernelGGL(light_classes_kernel, dim3((unsigned)(p.tiles_x * p.tiles_y)), dim3(64), 0, as_stream(stream), p, (unsigned long long *)a->workspace);
+        hipLaunchKernelGGL(light_classes_kernel, dim3(((unsigned)(p.tiles_x * p.tiles_y) + 3u) / 4u), dim3(256), 0, as_stream(stream), p, (unsigned long long *)a->workspace);
     p.light_begin = 0;
     do {
         p.light_end = a->n_lights - p.light_begin <= chunk + chunk / 2 ? a->n_lights : p.light_begin + chunk;  // no short tail launch
