@@ -395,7 +395,7 @@ def time_shadow_retile(f, device, reps: int = 5) -> dict:
             "bytes": 2 * lin.numel() * 4}
 
 
-def time_shadow_ranges(dev_frame, renderer, reps: int = 5) -> dict:
+def time_shadow_ranges(dev_frame, renderer, compare: bool = True, reps: int = 5) -> dict:
     """The depth ranges of the point-shadow cubes: how long they take to build (a caller whose shadow pass runs every
     frame pays this every frame), and the shading kernel without them on the same frame (every tap read: the
     shader's own access pattern), with the two images compared."""
@@ -413,15 +413,18 @@ def time_shadow_ranges(dev_frame, renderer, reps: int = 5) -> dict:
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
     build_ms = avg_ms(lambda: P.cube_shadow_ranges(dev_frame.cube_shadow, dev_frame.cube_layout, dev_frame.cube_ranges))
-    color, thr = torch.empty_like(renderer.color), torch.empty_like(renderer.threshold)
-    with_ms = avg_ms(lambda: P.shade(dev_frame, renderer.color, renderer.threshold))
-    plain = dataclasses.replace(dev_frame, cube_ranges=None)
-    without_ms = avg_ms(lambda: P.shade(plain, color, thr))
-    same = bool(torch.equal(color.view(torch.int16), renderer.color.view(torch.int16)) and torch.equal(thr.view(torch.int16), renderer.threshold.view(torch.int16)))
     cube_bytes = dev_frame.cube_shadow.numel() * 4
-    return {"build_ms": round(build_ms, 4), "build_reads_GB/s": round(cube_bytes / (build_ms * 1e-3) / 1e9, 1),
-            "bytes": dev_frame.cube_ranges.numel(), "cube_bytes": cube_bytes,
-            "shade_ms": round(with_ms, 4), "shade_ms_without_ranges": round(without_ms, 4), "same_image_without_ranges": same}
+    out = {"build_ms": round(build_ms, 4), "build_reads_GB/s": round(cube_bytes / (build_ms * 1e-3) / 1e9, 1),
+           "bytes": dev_frame.cube_ranges.numel(), "cube_bytes": cube_bytes,
+           "tile_classes_bytes": None if dev_frame.shade_workspace is None else dev_frame.shade_workspace.numel()}
+    if compare:
+        color, thr = torch.empty_like(renderer.color), torch.empty_like(renderer.threshold)
+        plain = dataclasses.replace(dev_frame, cube_ranges=None)
+        with_ms = avg_ms(lambda: P.shade(dev_frame, renderer.color, renderer.threshold))
+        without_ms = min(avg_ms(lambda: P.shade(plain, color, thr)) for _ in range(2))
+        same = bool(torch.equal(color.view(torch.int16), renderer.color.view(torch.int16)) and torch.equal(thr.view(torch.int16), renderer.threshold.view(torch.int16)))
+        out.update({"shade_ms": round(with_ms, 4), "shade_ms_without_ranges": round(without_ms, 4), "same_image_without_ranges": same})
+    return out
 
 
 def time_ibl(device, reps: int = 3) -> tuple[dict, list]:
@@ -758,6 +761,47 @@ def measured_counters(width: int, rows: int, lights: int, cube_res: int, dir_res
     return rec.get("kernels", {})
 
 
+PAIR_COUNT_FILE = "profiles/r3_shade_pair_counts.json"
+PAIR_COUNT_NAMES = ["no_live_lane", "one_face_settled_per_pixel_by_a_range", "one_face_taps_read", "edge_or_corner_taps_read",
+                    "all_live_lanes_fully_shadowed_no_brdf", "brdf_evaluated", "tile_class_skip", "tile_class_lit"]
+
+
+def shade_pair_counts(dev_frame, renderer) -> dict:
+    """Counts kept by a library built with -DVKR_EXPERIMENT_COUNT over one launch of the composition pass: how many
+    (wave, light) pairs the tile classes skipped or took as lit, how many the per-pixel range test settled, how many read
+    their 20 taps, how many evaluated the BRDF."""
+    import ctypes
+    import torch
+    from vulkanrenderer_amd import _lib, passes as P
+    lib = _lib.load()
+    fn = getattr(lib, "vkr_experiment_shade_counts", None)
+    if fn is None:
+        raise SystemExit("--pair-counts needs a library built with -DVKR_EXPERIMENT_COUNT (scratch/build_variant.sh, VKR_HIP_LIB)")
+    buf = (ctypes.c_ulonglong * 8)()
+    torch.cuda.synchronize()
+    fn(buf, 1)
+    P.shade(dev_frame, renderer.color, renderer.threshold)
+    torch.cuda.synchronize()
+    fn(buf, 1)
+    c = dict(zip(PAIR_COUNT_NAMES, (int(v) for v in buf)))
+    c["pairs"] = c["tile_class_skip"] + c["no_live_lane"] + c["tile_class_lit"] + c["one_face_settled_per_pixel_by_a_range"] + c["one_face_taps_read"] + c["edge_or_corner_taps_read"]
+    # a pair without a live lane is counted before the tile class is looked at; a lit tile with live lanes goes on to the BRDF
+    c["workload"] = {"width": dev_frame.width, "rows": dev_frame.rows, "lights": dev_frame.n_lights, "cube_res": dev_frame.cube_shadow.shape[-1]}
+    return c
+
+
+def stored_pair_counts(width: int, rows: int, lights: int, cube_res: int) -> dict:
+    try:
+        with open(os.path.join(ROOT, PAIR_COUNT_FILE)) as fh:
+            rec = json.load(fh)
+    except OSError:
+        return {}
+    if rec.get("workload") != {"width": width, "rows": rows, "lights": lights, "cube_res": cube_res}:
+        return {}
+    rec["source"] = f"{PAIR_COUNT_FILE}: one launch of this workload by a library built with -DVKR_EXPERIMENT_COUNT (bench.py --pair-counts), not counted in this run"
+    return rec
+
+
 def cpu_baseline(f, gpu_color, gpu_thr, sample_rows: int) -> dict:
     """The oracle (CPU restatement, OpenMP) on the first `sample_rows` rows of the same frame; also
     checks the GPU's rows against it bit for bit."""
@@ -839,6 +883,10 @@ def main() -> None:
     ap.add_argument("--cpu-rows", type=int, default=None, help="rows of the frame the CPU baseline shades (default: all; 0 = skip)")
     ap.add_argument("--no-ibl", action="store_true", help="skip the IBL precompute timing")
     ap.add_argument("--no-coverage", action="store_true", help="skip the light-volume coverage and shadow-pass timings")
+    ap.add_argument("--pair-counts", action="store_true", help="with a library built with -DVKR_EXPERIMENT_COUNT (VKR_HIP_LIB): what happens to the "
+                    "(wave, light) pairs of one launch of the shading kernel, added to the JSON line as shade_pair_counts")
+    ap.add_argument("--no-ranges-compare", action="store_true", help="do not launch the shading kernel without depth ranges beside the timed one "
+                    "(counter passes: every shade_kernel launch of the run is then the timed form)")
     ap.add_argument("--no-extra", action="store_true", help="N > 1: skip the extra shapes (a full strip per rank and the 16384-wide / 256-light strip)")
     ap.add_argument("--extra", action="store_true", help="N = 1: also time the 16384x2048 / 256-light strip (off by default, so that every launch of the "
                     "shading kernel in a default run has the shape the roofline is quoted on and a kernel trace of the run averages one shape)")
@@ -954,7 +1002,7 @@ def main() -> None:
     shade_tflops = flops / (kernel_ms["shade"] * 1e-3) / 1e12
     ctr = measured_counters(WIDTH, plan.rows, args.lights, args.cube_res, args.dir_res)
     shade_ctr = ctr.get("shade_kernel", {})
-    roofline = {"bound": "valu", "kernel": "shade_kernel", "achieved": round(shade_tflops, 3), "peak": PEAK_FP32_TFLOPS,
+    roofline = {"bound": "valu", "kernel": "shade_kernel" + (" (+ light_classes_kernel)" if dev_frame.cube_ranges is not None else ""), "achieved": round(shade_tflops, 3), "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(shade_tflops / PEAK_FP32_TFLOPS, 4), "traffic": shade_ctr.get("traffic_bytes"),
                 "traffic_source": f"{COUNTER_FILE}: separate rocprofv3 --pmc passes of this command, (2 x FETCH_SIZE + WRITE_SIZE) x 1024, not read in this run" if shade_ctr else None,
                 "algorithmic": f"({OPS_PER_PIXEL} + {OPS_PER_PIXEL_LIGHT} x {args.lights}) canonical FP32 ops x {shaded_px} shaded pixels per launch "
@@ -968,7 +1016,6 @@ def main() -> None:
         if shade_ctr.get("SQ_INSTS_VALU"):
             roofline["valu_lane_instructions"] = shade_ctr["SQ_INSTS_VALU"] * 64
             roofline["canonical_ops_per_lane_instruction"] = round(flops / (shade_ctr["SQ_INSTS_VALU"] * 64), 3)
-        roofline["wave_lights_without_taps_frac"] = shade_ctr.get("wave_lights_without_taps_frac")
         # how busy the two units are that bound the kernel (same counter file): the 256 texture addressers, against the
         # cycles the launch was active on an XCD; the vector ALUs, whose busy time is tallied in units of four cycles
         if shade_ctr.get("TA_TA_BUSY_sum") and shade_ctr.get("GRBM_GUI_ACTIVE"):
@@ -979,6 +1026,9 @@ def main() -> None:
                 roofline["addresser_cycles_per_gather"] = round(shade_ctr["TA_TA_BUSY_sum"] / shade_ctr["SQ_INSTS_VMEM_RD"], 2)
             if shade_ctr.get("SQ_ACTIVE_INST_VALU"):
                 roofline["valu_busy_frac"] = round(min(shade_ctr["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * cycles), 1.0), 3)
+    pair_counts = shade_pair_counts(dev_frame, renderer) if args.pair_counts else stored_pair_counts(WIDTH, plan.rows, args.lights, args.cube_res)
+    if pair_counts:
+        roofline["wave_light_pairs"] = pair_counts
     def hbm_rec(kernel, bytes_per_px, ms, algorithmic, ctr_name):
         gbs = bytes_per_px * strip_px / (ms * 1e-3) / 1e9
         return {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
@@ -1021,11 +1071,17 @@ def main() -> None:
             out["predicted_ibl_precompute_sharded"] = predict_ibl_sharded((1, 2, 4, 8) if world == 1 else (1, world), device)
     out.update(extra)
     if dev_frame.cube_ranges is not None:
-        sr = time_shadow_ranges(dev_frame, renderer)
-        sr["note"] = ("not part of a step: the ranges are built when the cubes change, as the cubes themselves are inputs of a step; "
-                      "ms_per_step + build_ms = a frame whose shadow pass ran and whose ranges were rebuilt")
+        sr = time_shadow_ranges(dev_frame, renderer, compare=not args.no_ranges_compare)
+        sr["note"] = ("build_ms is not part of a step: the ranges are built when the cubes change, as the cubes themselves are inputs of a step; "
+                      "ms_per_step + build_ms = a frame whose shadow pass ran and whose ranges were rebuilt.  The per-tile light classes "
+                      "are made from the G-buffer inside every step (light_classes_kernel, timed with the shading kernel)")
         sr["value_with_ranges_built_every_frame"] = round(px / ((ms_per_step + sr["build_ms"]) * 1e-3) / 1e6, 3)
-        sr["value_without_ranges"] = round(px / ((ms_per_step + sr["shade_ms_without_ranges"] - sr["shade_ms"]) * 1e-3) / 1e6, 3)
+        if "shade_ms_without_ranges" in sr:
+            sr["value_without_ranges"] = round(px / ((ms_per_step + sr["shade_ms_without_ranges"] - sr["shade_ms"]) * 1e-3) / 1e6, 3)
+            plain_tflops = flops / (sr["shade_ms_without_ranges"] * 1e-3) / 1e12
+            roofline["without_ranges"] = {"avg_launch_ms": sr["shade_ms_without_ranges"], "achieved": round(plain_tflops, 3),
+                                          "frac": round(plain_tflops / PEAK_FP32_TFLOPS, 4),
+                                          "note": "the same kernel reading all 20 taps of every light of every pixel, as light.frag does: the canonical count describes this form"}
         out["shadow_ranges"] = sr
     if world == 1 and dev_frame.cube_layout != 0:
         rt = time_shadow_retile(f, device)

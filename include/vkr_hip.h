@@ -157,11 +157,12 @@ typedef struct VkrShadeArgs {
     const uint32_t *coverage_flags;               /* VKR_COVERAGE_MESH: VkrCoverageArgs.light_flags of the call that wrote
                                                      coverage_masks, or NULL; when it says that every light covers every
                                                      pixel the masks are not read */
-    const void *cube_ranges;                      /* depth ranges of cube_shadow written by vkr_cube_shadow_ranges(), or NULL:
-                                                     same output either way, fewer shadow-map fetches with them */
-    void *workspace;                              /* with cube_ranges: device memory of vkr_shade_workspace_bytes() for the
-                                                     per-tile light classes (lights whose taps are settled for a whole 8x8
-                                                     tile are skipped or taken as lit before any per-pixel work), or NULL */
+    const void *cube_ranges;                      /* depth ranges of cube_shadow written by vkr_cube_shadow_ranges(), or NULL */
+    void *workspace;                              /* device memory of vkr_shade_workspace_bytes() bytes, or NULL.  With both
+                                                     cube_ranges and workspace the pass first sorts the lights of every 8x8
+                                                     tile by what the ranges prove for all of the tile's pixels (all 20 taps
+                                                     in shadow: the light is skipped; none: taken as lit; else: taps read),
+                                                     written to workspace.  Same output either way, bit for bit. */
     int64_t workspace_bytes;
 } VkrShadeArgs;
 VKR_EXPORT int64_t vkr_shade_workspace_bytes(int32_t width, int32_t rows, int32_t n_lights);
@@ -169,10 +170,10 @@ VKR_EXPORT int32_t vkr_shade(const VkrShadeArgs *args, void *stream);
 
 /* Depth ranges of the cube shadow maps, an acceleration structure for vkr_shade with no counterpart in the reference
  * (light.frag:131-137 reads its 20 taps per light unconditionally): the smallest and largest value the taps compare
- * against over half-overlapping blocks of each face, at four block sizes.  Where one range shows that all 20 taps of a
- * pixel are in shadow, or none, vkr_shade takes that count without reading the taps; the image is the same bit for bit.
- * `ranges` is device memory of vkr_cube_shadow_ranges_bytes(n_lights, res) bytes; rebuild it whenever `cubes` changes.
- * `layout` is the VKR_CUBE_LAYOUT_* of `cubes`. */
+ * against over half-overlapping blocks of each face, at four block sizes.  Where one range shows that all 20 taps of
+ * every pixel of an 8x8 tile are in shadow, or none, vkr_shade takes that outcome without reading the taps; the image is
+ * the same bit for bit.  `ranges` is device memory of vkr_cube_shadow_ranges_bytes(n_lights, res) bytes; rebuild it
+ * whenever `cubes` changes.  `layout` is the VKR_CUBE_LAYOUT_* of `cubes`. */
 VKR_EXPORT int64_t vkr_cube_shadow_ranges_bytes(int32_t n_lights, int32_t res);
 VKR_EXPORT int32_t vkr_cube_shadow_ranges(const float *cubes, int32_t n_lights, int32_t res, int32_t layout, void *ranges, void *stream);
 

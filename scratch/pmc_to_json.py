@@ -6,7 +6,7 @@ random-line read rates of scratch/ubench/gather_bench."""
 import collections, csv, glob, json, sys
 
 root, out = sys.argv[1], sys.argv[2]
-KERNELS = {"shade_kernel": "shade_kernel", "bloom_post_fused_kernel": "bloom_post_fused", "bloom_h_kernel": "bloom_h_kernel", "bloom_v_kernel": "bloom_v_kernel"}
+KERNELS = {"shade_kernel": "shade_kernel", "light_classes_kernel": "light_classes_kernel", "bloom_post_fused_kernel": "bloom_post_fused", "bloom_h_kernel": "bloom_h_kernel", "bloom_v_kernel": "bloom_v_kernel"}
 acc = {k: collections.defaultdict(list) for k in KERNELS}
 for path in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     with open(path) as fh:
@@ -17,7 +17,7 @@ for path in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
 W, H, L = 3840, 2160, 64
 rec = {"_comment": "Per-launch means of rocprofv3 --pmc counters, one pass per counter group (scratch/pmc_frame.sh). traffic_bytes = "
                    "(2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE and WRITE_SIZE are in KiB and on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes.",
-       "command": "rocprofv3 --pmc <counters> -- python3 bench.py --steps 3 --warmup 1 --no-ibl --no-coverage --cpu-rows 0",
+       "command": "rocprofv3 --pmc <counters> -- python3 bench.py --steps 3 --warmup 1 --no-ibl --no-coverage --no-ranges-compare --cpu-rows 0",
        "workload": {"width": W, "rows": H, "lights": L, "cube_res": 1024, "dir_res": 4096}, "kernels": {}}
 for k, ctr in acc.items():
     if not ctr:
@@ -31,13 +31,6 @@ for k, ctr in acc.items():
     for n in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_BUSY_CYCLES", "TA_TA_BUSY_sum", "GRBM_GUI_ACTIVE"):
         if n in m:
             e[n] = int(round(m[n]))
-    if k == "shade_kernel" and "SQ_INSTS_VMEM_RD" in m and "SQ_WAVES" in m:
-        # a (wave, light) pair that samples its shadow cube issues 20 gathers; outside the light loop a wave issues about 25
-        # loads (G-buffer, 9 directional-shadow taps, the three IBL lookups)
-        waves = m["SQ_WAVES"]
-        taps = (m["SQ_INSTS_VMEM_RD"] - 25 * waves) / 20.0
-        e["wave_lights_without_taps_frac"] = round(1.0 - taps / (waves * L), 4)
-        e["wave_lights_without_taps_note"] = "1 - (SQ_INSTS_VMEM_RD - 25 x waves) / (20 x waves x lights): pairs skipped because the wave faces away from the light or is cleared background"
     rec["kernels"][k] = e
 if len(sys.argv) > 4:
     import re

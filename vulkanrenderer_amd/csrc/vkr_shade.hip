@@ -236,14 +236,16 @@ VKR_DEV float taps_one_face(const float *face_base, int res, const float (&X)[3]
     return count + count_a;  // an integer in [0, 20], exact in binary32
 }
 
-// Depth ranges of the cube maps: a coarse image beside each face that lets most lights of most waves be settled by one
-// fetch instead of twenty.  Level k (0..RANGE_LEVELS-1) holds, for every block of 2S x 2S texels at stride S = RANGE_CELL << k
-// in both directions (block (bx, by) covers columns [bx S, bx S + 2S) and rows [by S, by S + 2S), cut at the face's edge),
-// the smallest and the largest of the values the taps compare against (25 x depth, rounded as the taps round it).  Blocks
-// overlap by half, so a window of texels no wider than S lies inside the block that holds its first column and row.
-// A block with a NaN in it holds (-inf, +inf) and settles nothing.
-// Memory: [light][level][face][cells][cells] pairs of floats with cells = ceil(res / RANGE_CELL) at every level (rows
-// and slabs of the coarser levels are padded to the size of level 0, which keeps the address arithmetic uniform).
+// Depth ranges of the cube maps: a coarse image beside each face from which light_classes_kernel settles most lights of
+// most 8x8-pixel tiles with one fetch, where the shader reads twenty texels per pixel.  Level k (0..RANGE_LEVELS-1) holds,
+// for every block of 2S x 2S texels at stride S = RANGE_CELL << k in both directions (block (bx, by) covers columns
+// [bx S, bx S + 2S) and rows [by S, by S + 2S), cut at the face's edge), the smallest and the largest of the values the
+// taps compare against (25 x depth, rounded as the taps round it).  Blocks overlap by half, so a window of texels
+// narrower than S lies inside the block that holds its first column and row: with i0 the first column and bx = i0 / S,
+// the last column is below i0 + S < (bx + 2) S.  A block with a NaN in it holds (-inf, +inf) and settles nothing.
+// Memory: [light][slab][face][cells][cells] pairs of floats with cells = ceil(res / RANGE_CELL); slab k < RANGE_LEVELS is
+// level k (rows and slabs of the coarser levels are padded to the size of level 0, which keeps the address arithmetic
+// uniform; the padding is (-inf, +inf) and never read), slab RANGE_LEVELS the cells the levels are built from.
 static constexpr int RANGE_CELL = 16, RANGE_LEVELS = 4;
 
 #ifdef VKR_EXPERIMENT_COUNT  // kernel experiments only: what happens to each (wave, light) pair
@@ -252,42 +254,6 @@ __device__ unsigned long long shade_counts[8];
 #else
 #define VKR_COUNT(i) do { } while (0)
 #endif
-
-// The one-face case again: are the 20 comparisons of this lane all true, or all false?  A tap's column is
-// floor(t) for t = (u / m) h + h evaluated in binary32 (h = res / 2), with u within r of the centre's u0 and |m| within
-// r of the centre's |m0|: in exact arithmetic |t - t0| <= HW = h r (1 + |u0 / m0|) / (|m0| - r), and three roundings of
-// relative size 2^-24 move a t of at most 2^13 by less than 2^-9, so every tap column lies within floor(HW) + 3 of the
-// centre's own column as computed here from hardware reciprocals (one more unit in the last place, the same argument);
-// rows likewise.  `hr` is h r (1 + 2^-8), the margin that covers the roundings of this bound itself.  The window of
-// half-width hw around the centre, cut at the face's edge, is less than S = 16 << level wide for level = bits(hw >> 3),
-// so the block of that level that holds its first column and row covers it.  One range over that block then bounds
-// every texel a tap can read: cur > largest means 20 taps in shadow, not (cur > smallest) means none -- the very
-// comparison of step_closer.  Returns whether the lane is settled and, if so, its count (0 or 20) in `count`.
-template <int AXIS, bool POW2>
-VKR_DEV bool taps_settled_by_ranges(const float2 *face_ranges, unsigned cells, int res, float fx, float fy, float fz, float r, float hr, float cur, float &count)
-{
-    const float fres = (float)res;
-    const float m0 = AXIS == 2 ? fz : (AXIS == 1 ? fy : fx);
-    const float rs = __builtin_amdgcn_rcpf(m0), ru = __builtin_fabsf(rs);
-    float u, ur, w, wr;  // the face coordinates of the centre, by the rules of taps_one_face
-    if (AXIS == 2) { u = fx; ur = rs; w = -fy; wr = ru; }
-    else if (AXIS == 1) { u = fx; ur = ru; w = fz; wr = rs; }
-    else { u = -fz; ur = rs; w = -fy; wr = ru; }
-    const float qu = u * ur, qw = w * wr;
-    const int ci = face_texel_inside<POW2>(u, ur, fres), cj = face_texel_inside<POW2>(w, wr, fres);
-    const float k = hr * __builtin_amdgcn_rcpf(__builtin_fabsf(m0) - r), k3 = k + 3.0f;
-    const float hwf = __builtin_fmaxf(fma_(__builtin_fabsf(qu), k, k3), fma_(__builtin_fabsf(qw), k, k3));
-    int hw;
-    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(hw) : "v"(__builtin_fminf(hwf, 0x1p20f)));
-    const unsigned level = 32u - (unsigned)__clz(hw >> 3);                // smallest k with 2 hw < 16 << k
-    const unsigned shift = 4u + level;
-    const unsigned i_lo = (unsigned)max(ci - hw, 0), j_lo = (unsigned)max(cj - hw, 0);
-    const unsigned slab = min(level, (unsigned)RANGE_LEVELS - 1u) * 6u;   // an unsettled lane still reads inside the array
-    const float2 range = face_ranges[__umul24(__umul24(slab, cells) + (j_lo >> shift), cells) + (i_lo >> shift)];
-    const bool all_closer = cur > range.y, none_closer = !(cur > range.x);
-    count = all_closer ? 20.0f : 0.0f;
-    return level < (unsigned)RANGE_LEVELS && (all_closer || none_closer);
-}
 
 // The count for a wave that straddles a cube edge or corner: the face is chosen per tap and per lane
 // (light.frag:133 through shadowSampler: NEAREST on the face the direction's major axis selects; ties go
@@ -548,7 +514,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     if (!degenerate_normal) {
         const float disk = fma_(view_distance, 1.0f / 25.0f, 1.0f) * (1.0f / 25.0f);
         const float fourNdotV = 4.0f * NdotV;
-        const float range_hr = (0.5f * (float)p.cube_res * (1.0f + 0x1p-8f)) * disk;  // see taps_settled_by_ranges
         const size_t face_stride = (size_t)p.cube_res * p.cube_res;
         auto rcp_fast = [](float v) { return fast_rcp_rn(v); };
         // Light records are read-only for the whole launch and their address is wave-uniform: read
@@ -586,7 +551,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                     skip_word = classes_c[(li >> 6) * 2];
                     lit_word = classes_c[(li >> 6) * 2 + 1];
                 }
-                if ((skip_word >> (li & 63)) & 1ull) continue;  // every pixel of the tile has all 20 taps in shadow: adds exactly zero
+                if ((skip_word >> (li & 63)) & 1ull) { VKR_COUNT(6); continue; }  // every pixel of the tile has all 20 taps in shadow: adds exactly zero
             }
             const bool tile_lit = (lit_word >> (li & 63)) & 1ull;  // no tap of any pixel of the tile is in shadow
             bool covered = true;
@@ -629,24 +594,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             const int face0 = tile_lit ? -2 : wave_common_face(Fv.x, Fv.y, Fv.z, disk);
             float count;
             if (tile_lit) {
+                VKR_COUNT(7);
                 count = 0.0f;
             } else if (face0 >= 0) {
-                bool settled = false;
-                if (p.cube_ranges) {  // one fetch of a depth range may stand for the 20 taps, for every lane that matters
-                    const float2 *fr = p.cube_ranges + ((size_t)li * ((RANGE_LEVELS + 1) * 6) + face0) * p.range_cells * p.range_cells;
-                    bool lane_settled;
-                    if (face0 >= 4) lane_settled = taps_settled_by_ranges<2, POW2>(fr, p.range_cells, p.cube_res, Fv.x, Fv.y, Fv.z, disk, range_hr, cur, count);
-                    else if (face0 >= 2) lane_settled = taps_settled_by_ranges<1, POW2>(fr, p.range_cells, p.cube_res, Fv.x, Fv.y, Fv.z, disk, range_hr, cur, count);
-                    else lane_settled = taps_settled_by_ranges<0, POW2>(fr, p.range_cells, p.cube_res, Fv.x, Fv.y, Fv.z, disk, range_hr, cur, count);
-                    settled = (live & ~__builtin_amdgcn_ballot_w64(lane_settled)) == 0ull;
-                    if (settled) VKR_COUNT(1); else VKR_COUNT(2);
-                }
-                if (!settled) {
-                    const float *fb = cube + (size_t)face0 * face_stride;
-                    if (face0 >= 4) count = taps_one_face<2, TILED, POW2, X25>(fb, p.cube_res, X, Y, Z, cur);
-                    else if (face0 >= 2) count = taps_one_face<1, TILED, POW2, X25>(fb, p.cube_res, X, Y, Z, cur);
-                    else count = taps_one_face<0, TILED, POW2, X25>(fb, p.cube_res, X, Y, Z, cur);
-                }
+                VKR_COUNT(2);
+                const float *fb = cube + (size_t)face0 * face_stride;
+                if (face0 >= 4) count = taps_one_face<2, TILED, POW2, X25>(fb, p.cube_res, X, Y, Z, cur);
+                else if (face0 >= 2) count = taps_one_face<1, TILED, POW2, X25>(fb, p.cube_res, X, Y, Z, cur);
+                else count = taps_one_face<0, TILED, POW2, X25>(fb, p.cube_res, X, Y, Z, cur);
             } else {  // the wave straddles a cube edge or corner
                 VKR_COUNT(3);
                 const unsigned axes = wave_major_axes(Fv.x, Fv.y, Fv.z, disk);
@@ -878,7 +833,7 @@ VKR_DEV float wave_max_uniform(float v)
 //   a face coordinate is then +-u / |m| with u and |m| in known intervals: its extremes lie at the intervals' ends.
 //   Texel indices are floors of values below 2^13 evaluated with relative errors of a few 2^-24 here and in the
 //   shading kernel, so both floors are within 1 of the exact one: the window is widened by 2 texels on every side.
-// A window narrower than S = 16 << level lies inside one block of that level (see taps_settled_by_ranges); its range
+// A window narrower than S = 16 << level lies inside one block of that level (see RANGE_CELL); its range
 // against cur_min / cur_max decides.  Tiles with a non-finite position or disk radius among their pixels, distances
 // outside the range where the kernel's own skip is valid (2^-96 <= |fragToLight|^2 <= 2^96), or windows too wide,
 // get neither bit, and the shading kernel decides per pixel as before.
