@@ -893,46 +893,67 @@ __global__ __launch_bounds__(256) void light_classes_kernel(const ShadeParams p,
             const bool in_domain = d2_min >= 0x1p-96f && d2_max <= 0x1p96f;  // false for NaN
             // both roots are correctly rounded inside the domain just tested, and unused outside it
             const float cur_min = fast_sqrt_rn(d2_min) - 0.15f, cur_max = fast_sqrt_rn(d2_max) - 0.15f;
-            // at most one coordinate can exceed both others over all candidates
-            const bool z_major = c_min[2] > __builtin_fmaxf(c_max[0], c_max[1]), y_major = c_min[1] > __builtin_fmaxf(c_max[0], c_max[2]);
-            const bool x_major = c_min[0] > __builtin_fmaxf(c_max[1], c_max[2]);
-            const int m = z_major ? 2 : (y_major ? 1 : 0);
-            const float m_min = z_major ? c_min[2] : (y_major ? c_min[1] : c_min[0]), m_max = z_major ? c_max[2] : (y_major ? c_max[1] : c_max[0]);
-            const float m_hi = z_major ? c_hi[2] : (y_major ? c_hi[1] : c_hi[0]);
-            const bool one_face = (z_major || y_major || x_major) && m_max < 0x1p100f;
-            if (in_domain && one_face) {
-                const bool negative = m_hi < 0.0f;
-                const int face = m * 2 + (negative ? 1 : 0);
-                // sc and tc: which coordinate, and the sign it is taken with (taps_one_face)
-                int su_axis, sw_axis; float su_sign, sw_sign;
-                const float sgn = negative ? -1.0f : 1.0f;
-                if (m == 2) { su_axis = 0; su_sign = sgn; sw_axis = 1; sw_sign = -1.0f; }
-                else if (m == 1) { su_axis = 0; su_sign = 1.0f; sw_axis = 2; sw_sign = sgn; }
-                else { su_axis = 2; su_sign = -sgn; sw_axis = 1; sw_sign = -1.0f; }
-                const float r_small = __builtin_amdgcn_rcpf(m_max), r_large = __builtin_amdgcn_rcpf(m_min);  // one unit in the last place off at most
-                auto window = [&](int axis, float sign, int &first, int &last) {
-                    float u_lo = axis == 0 ? c_lo[0] : (axis == 1 ? c_lo[1] : c_lo[2]);
-                    float u_hi = axis == 0 ? c_hi[0] : (axis == 1 ? c_hi[1] : c_hi[2]);
-                    if (sign < 0.0f) { const float t = u_lo; u_lo = -u_hi; u_hi = -t; }
-                    const float q_lo = __builtin_fminf(u_lo * r_small, u_lo * r_large), q_hi = __builtin_fmaxf(u_hi * r_small, u_hi * r_large);
-                    const float t_lo = fma_(q_lo, half, half), t_hi = fma_(q_hi, half, half);  // within (0, res): |u| < |m|
-                    first = max((int)__builtin_floorf(t_lo) - 2, 0);
-                    last = min((int)__builtin_floorf(t_hi) + 2, p.cube_res - 1);
-                };
-                int i0, i1, j0, j1;
-                window(su_axis, su_sign, i0, i1);
-                window(sw_axis, sw_sign, j0, j1);
-                const unsigned width = (unsigned)max(max(i1 - i0, j1 - j0), 0);
-                const unsigned level = 32u - (unsigned)__clz((int)(width >> 4));  // smallest k with width < 16 << k
-                if (level < (unsigned)RANGE_LEVELS) {
+            // The faces a tap can select: major coordinate m with sign s needs a candidate of that sign whose magnitude
+            // reaches the smallest magnitudes of both other coordinates.  Bit 2m + (s < 0).
+            unsigned possible = 0u;
+#pragma unroll
+            for (int m = 0; m < 3; m++) {
+                const float need = __builtin_fmaxf(c_min[(m + 1) % 3], c_min[(m + 2) % 3]);
+                if (c_hi[m] > 0.0f && c_hi[m] >= need) possible |= 1u << (2 * m);
+                if (c_lo[m] < 0.0f && -c_lo[m] >= need) possible |= 2u << (2 * m);
+            }
+            bool decided = in_domain && possible != 0u;  // until a face says otherwise
+            float nearest = inf, farthest = -inf;        // over the ranges of every face a tap can fall on
+            // One face in most tiles, two along a cube edge, three at a corner: more (a light inside the tile's box) are left
+            // to the per-pixel path.  The lanes of a wave are different lights, so the trip count is the wave's largest.
+            for (int trip = 0; trip < 3 && wave_any(decided && possible != 0u); trip++) {
+                if (decided && possible != 0u) {
+                    const int face = __builtin_ctz(possible);
+                    possible &= possible - 1u;
+                    const int m = face >> 1;
+                    const bool negative = face & 1;
+                    const float side_lo = m == 2 ? c_lo[2] : (m == 1 ? c_lo[1] : c_lo[0]), side_hi = m == 2 ? c_hi[2] : (m == 1 ? c_hi[1] : c_hi[0]);
+                    // |major| over the taps of this face: on this side of zero, and at least every other coordinate's magnitude
+                    const float m_max = negative ? -side_lo : side_hi;
+                    const float others = __builtin_fmaxf(m == 0 ? c_min[1] : c_min[0], m == 2 ? c_min[1] : c_min[2]);
+                    const float m_min = __builtin_fmaxf(__builtin_fmaxf(negative ? -side_hi : side_lo, others), 0.0f);
+                    if (!(m_min > 0.0f && m_max < 0x1p100f)) { decided = false; continue; }
+                    // sc and tc: which coordinate, and the sign it is taken with (taps_one_face)
+                    int su_axis, sw_axis; float su_sign, sw_sign;
+                    const float sgn = negative ? -1.0f : 1.0f;
+                    if (m == 2) { su_axis = 0; su_sign = sgn; sw_axis = 1; sw_sign = -1.0f; }
+                    else if (m == 1) { su_axis = 0; su_sign = 1.0f; sw_axis = 2; sw_sign = sgn; }
+                    else { su_axis = 2; su_sign = -sgn; sw_axis = 1; sw_sign = -1.0f; }
+                    const float r_small = __builtin_amdgcn_rcpf(m_max), r_large = __builtin_amdgcn_rcpf(m_min);  // one unit in the last place off at most
+                    auto window = [&](int axis, float sign, int &first, int &last) {
+                        float u_lo = axis == 0 ? c_lo[0] : (axis == 1 ? c_lo[1] : c_lo[2]);
+                        float u_hi = axis == 0 ? c_hi[0] : (axis == 1 ? c_hi[1] : c_hi[2]);
+                        if (sign < 0.0f) { const float t = u_lo; u_lo = -u_hi; u_hi = -t; }
+                        // a tap on this face has |u| <= |major|: beyond +-1 (plus a rounding, absorbed by the 2 texels) lie only
+                        // quotients of candidates that select another face
+                        const float q_lo = __builtin_fmaxf(__builtin_fminf(u_lo * r_small, u_lo * r_large), -1.0f);
+                        const float q_hi = __builtin_fminf(__builtin_fmaxf(u_hi * r_small, u_hi * r_large), 1.0f);
+                        const float t_lo = fma_(q_lo, half, half), t_hi = fma_(q_hi, half, half);
+                        first = max((int)__builtin_floorf(t_lo) - 2, 0);
+                        last = min((int)__builtin_floorf(t_hi) + 2, p.cube_res - 1);
+                    };
+                    int i0, i1, j0, j1;
+                    window(su_axis, su_sign, i0, i1);
+                    window(sw_axis, sw_sign, j0, j1);
+                    const unsigned width = (unsigned)max(max(i1 - i0, j1 - j0), 0);
+                    const unsigned level = 32u - (unsigned)__clz((int)(width >> 4));  // smallest k with width < 16 << k
+                    if (level >= (unsigned)RANGE_LEVELS) { decided = false; continue; }
                     const unsigned shift = 4u + level;
                     const size_t per_face = (size_t)p.range_cells * p.range_cells;
                     const float2 range = p.cube_ranges[(((size_t)li * (RANGE_LEVELS + 1) + level) * 6u + (unsigned)face) * per_face +
                                                        (size_t)((unsigned)j0 >> shift) * p.range_cells + ((unsigned)i0 >> shift)];
-                    skip = cur_min > range.y;
-                    lit = !(cur_max > range.x);
+                    nearest = __builtin_fminf(nearest, range.x);
+                    farthest = __builtin_fmaxf(farthest, range.y);
                 }
             }
+            decided = decided && possible == 0u;
+            skip = decided && cur_min > farthest;
+            lit = decided && !(cur_max > nearest);
         }
         const unsigned long long skip_mask = __builtin_amdgcn_ballot_w64(skip), lit_mask = __builtin_amdgcn_ballot_w64(lit);
         if (lane == 0) {
