@@ -28,7 +28,15 @@ for k in range(4):
     a, b = pad(mn1, np.inf), pad(mx1, -np.inf)
     lv.append((np.minimum.reduce([a[:, :, :-1, :-1], a[:, :, 1:, :-1], a[:, :, :-1, 1:], a[:, :, 1:, 1:]]),
                np.maximum.reduce([b[:, :, :-1, :-1], b[:, :, 1:, :-1], b[:, :, :-1, 1:], b[:, :, 1:, 1:]])))
-n = len(sel); tot = n * L; skip = lit = 0
+lv2 = []   # stride s = 8 << k, blocks of 4s: a window narrower than 3s lies in the block of its first column and row
+for k in range(4):
+    st = 8 << k; nb = RES // st
+    cm = cubes.reshape(L, 6, nb, st, nb, st)
+    mn1 = cm.min(axis=(3, 5)); mx1 = cm.max(axis=(3, 5))
+    a = np.pad(mn1, ((0, 0), (0, 0), (0, 3), (0, 3)), constant_values=np.inf); b = np.pad(mx1, ((0, 0), (0, 0), (0, 3), (0, 3)), constant_values=-np.inf)
+    lv2.append((np.minimum.reduce([a[:, :, dy:dy + nb, dx:dx + nb] for dy in range(4) for dx in range(4)]),
+                np.maximum.reduce([b[:, :, dy:dy + nb, dx:dx + nb] for dy in range(4) for dx in range(4)])))
+n = len(sel); tot = n * L; skip = lit = 0; skip2 = lit2 = 0; skip3 = lit3 = 0
 for i in range(L):
     lo3, hi3 = pmin - lights["position"][i], pmax - lights["position"][i]
     amin = np.where((lo3 <= 0) & (hi3 >= 0), 0, np.minimum(np.abs(lo3), np.abs(hi3))); amax = np.maximum(np.abs(lo3), np.abs(hi3))
@@ -55,4 +63,28 @@ for i in range(L):
         lo = lv[k][0][i, face[m], j0[m] // S, i0[m] // S]; hi = lv[k][1][i, face[m], j0[m] // S, i0[m] // S]
         s_skip[m] = cur_min[m] > hi; s_lit[m] = cur_max[m] <= lo
     skip += s_skip.sum(); lit += s_lit.sum()
+    level3 = np.full(n, 9)   # smallest level whose block at the window's first column and row holds the window, by alignment
+    for k in range(3, -1, -1):
+        S = 16 << k
+        fits = ((i0 // S) * S + 2 * S > i1) & ((j0 // S) * S + 2 * S > j1)
+        level3[fits] = k
+    ok3 = one & (level3 < 4)
+    u_skip = np.zeros(n, bool); u_lit = np.zeros(n, bool)
+    for k in range(4):
+        m = ok3 & (level3 == k); S = 16 << k
+        lo = lv[k][0][i, face[m], j0[m] // S, i0[m] // S]; hi = lv[k][1][i, face[m], j0[m] // S, i0[m] // S]
+        u_skip[m] = cur_min[m] > hi; u_lit[m] = cur_max[m] <= lo
+    skip3 += u_skip.sum(); lit3 += u_lit.sum()
+    level2 = np.full(n, 9)
+    for k in range(3, -1, -1):
+        level2[width < 3 * (8 << k)] = k
+    ok2 = one & (level2 < 4)
+    t_skip = np.zeros(n, bool); t_lit = np.zeros(n, bool)
+    for k in range(4):
+        m = ok2 & (level2 == k); st = 8 << k
+        lo = lv2[k][0][i, face[m], j0[m] // st, i0[m] // st]; hi = lv2[k][1][i, face[m], j0[m] // st, i0[m] // st]
+        t_skip[m] = cur_min[m] > hi; t_lit[m] = cur_max[m] <= lo
+    skip2 += t_skip.sum(); lit2 += t_lit.sum()
+print(f"by alignment: skip {skip3 / tot:.3f}  lit {lit3 / tot:.3f}  general {(tot - skip3 - lit3) / tot:.3f}")
+print(f"denser blocks: skip {skip2 / tot:.3f}  lit {lit2 / tot:.3f}  general {(tot - skip2 - lit2) / tot:.3f}")
 print(f"tile-level: skip {skip / tot:.3f}  lit {lit / tot:.3f}  general {(tot - skip - lit) / tot:.3f}")

@@ -941,7 +941,13 @@ __global__ __launch_bounds__(256) void light_classes_kernel(const ShadeParams p,
                     window(su_axis, su_sign, i0, i1);
                     window(sw_axis, sw_sign, j0, j1);
                     const unsigned width = (unsigned)max(max(i1 - i0, j1 - j0), 0);
-                    const unsigned level = 32u - (unsigned)__clz((int)(width >> 4));  // smallest k with width < 16 << k
+                    unsigned level = 32u - (unsigned)__clz((int)(width >> 4));  // smallest k with width < 16 << k: its block always holds the window
+                    // by where it starts, the window may also lie inside the half-sized block of the level below: columns
+                    // [bx S', bx S' + 2 S') with S' = S / 2, bx = i0 / S' (no deeper: the window is at least S' wide)
+                    if (level >= 1u && level <= (unsigned)RANGE_LEVELS) {
+                        const unsigned sh = 3u + level;
+                        if (((((unsigned)i0 >> sh) + 2u) << sh) > (unsigned)i1 && ((((unsigned)j0 >> sh) + 2u) << sh) > (unsigned)j1) level -= 1u;
+                    }
                     if (level >= (unsigned)RANGE_LEVELS) { decided = false; continue; }
                     const unsigned shift = 4u + level;
                     const size_t per_face = (size_t)p.range_cells * p.range_cells;
