@@ -28,6 +28,16 @@ for k in range(4):
     a, b = pad(mn1, np.inf), pad(mx1, -np.inf)
     lv.append((np.minimum.reduce([a[:, :, :-1, :-1], a[:, :, 1:, :-1], a[:, :, :-1, 1:], a[:, :, 1:, 1:]]),
                np.maximum.reduce([b[:, :, :-1, :-1], b[:, :, 1:, :-1], b[:, :, :-1, 1:], b[:, :, 1:, 1:]])))
+lv8 = []
+for k in range(5):
+    S = 8 << k; nb = RES // S
+    cm = cubes.reshape(L, 6, nb, S, nb, S)
+    mn1 = cm.min(axis=(3, 5)); mx1 = cm.max(axis=(3, 5))
+    pad = lambda a, fill: np.pad(a, ((0, 0), (0, 0), (0, 1), (0, 1)), constant_values=fill)
+    a, b = pad(mn1, np.inf), pad(mx1, -np.inf)
+    lv8.append((np.minimum.reduce([a[:, :, :-1, :-1], a[:, :, 1:, :-1], a[:, :, :-1, 1:], a[:, :, 1:, 1:]]),
+                np.maximum.reduce([b[:, :, :-1, :-1], b[:, :, 1:, :-1], b[:, :, :-1, 1:], b[:, :, 1:, 1:]])))
+skip4 = lit4 = 0
 lv2 = []   # stride s = 8 << k, blocks of 4s: a window narrower than 3s lies in the block of its first column and row
 for k in range(4):
     st = 8 << k; nb = RES // st
@@ -50,7 +60,7 @@ for i in range(L):
     def win(o):
         ulo, uhi = lo3[idx, o] - disk, hi3[idx, o] + disk
         q = [ulo / Mmin, ulo / Mmax, uhi / Mmin, uhi / Mmax]
-        a = np.floor((np.minimum.reduce(q) * 0.5 + 0.5) * RES) - 2; b = np.floor((np.maximum.reduce(q) * 0.5 + 0.5) * RES) + 2
+        a = np.floor((np.minimum.reduce(q) * 0.5 + 0.5) * RES); b = np.floor((np.maximum.reduce(q) * 0.5 + 0.5) * RES)
         return np.clip(a, 0, RES - 1).astype(int), np.clip(b, 0, RES - 1).astype(int)
     with np.errstate(all="ignore"):
         i0, i1 = win(o1); j0, j1 = win(o2)
@@ -75,6 +85,18 @@ for i in range(L):
         lo = lv[k][0][i, face[m], j0[m] // S, i0[m] // S]; hi = lv[k][1][i, face[m], j0[m] // S, i0[m] // S]
         u_skip[m] = cur_min[m] > hi; u_lit[m] = cur_max[m] <= lo
     skip3 += u_skip.sum(); lit3 += u_lit.sum()
+    level4 = np.full(n, 9)
+    for k in range(4, -1, -1):
+        S = 8 << k
+        fits = ((i0 // S) * S + 2 * S > i1) & ((j0 // S) * S + 2 * S > j1)
+        level4[fits] = k
+    ok4 = one & (level4 < 5)
+    v_skip = np.zeros(n, bool); v_lit = np.zeros(n, bool)
+    for k in range(5):
+        m = ok4 & (level4 == k); S = 8 << k
+        lo = lv8[k][0][i, face[m], j0[m] // S, i0[m] // S]; hi = lv8[k][1][i, face[m], j0[m] // S, i0[m] // S]
+        v_skip[m] = cur_min[m] > hi; v_lit[m] = cur_max[m] <= lo
+    skip4 += v_skip.sum(); lit4 += v_lit.sum()
     level2 = np.full(n, 9)
     for k in range(3, -1, -1):
         level2[width < 3 * (8 << k)] = k
@@ -85,6 +107,7 @@ for i in range(L):
         lo = lv2[k][0][i, face[m], j0[m] // st, i0[m] // st]; hi = lv2[k][1][i, face[m], j0[m] // st, i0[m] // st]
         t_skip[m] = cur_min[m] > hi; t_lit[m] = cur_max[m] <= lo
     skip2 += t_skip.sum(); lit2 += t_lit.sum()
+print(f"by alignment, five levels from 8: skip {skip4 / tot:.3f}  lit {lit4 / tot:.3f}  general {(tot - skip4 - lit4) / tot:.3f}")
 print(f"by alignment: skip {skip3 / tot:.3f}  lit {lit3 / tot:.3f}  general {(tot - skip3 - lit3) / tot:.3f}")
 print(f"denser blocks: skip {skip2 / tot:.3f}  lit {lit2 / tot:.3f}  general {(tot - skip2 - lit2) / tot:.3f}")
 print(f"tile-level: skip {skip / tot:.3f}  lit {lit / tot:.3f}  general {(tot - skip - lit) / tot:.3f}")

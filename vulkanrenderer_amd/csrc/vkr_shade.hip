@@ -831,8 +831,11 @@ VKR_DEV float wave_max_uniform(float v)
 //   when the smallest magnitude of one coordinate's candidates exceeds the largest of both others, every tap of
 //   every pixel selects that face (ties cannot occur) and the sign of the major coordinate is fixed;
 //   a face coordinate is then +-u / |m| with u and |m| in known intervals: its extremes lie at the intervals' ends.
-//   Texel indices are floors of values below 2^13 evaluated with relative errors of a few 2^-24 here and in the
-//   shading kernel, so both floors are within 1 of the exact one: the window is widened by 2 texels on every side.
+//   Texel indices are floors of t = q res / 2 + res / 2 <= 2^13, which the shading kernel evaluates from a correctly
+//   rounded reciprocal, a product and an fma (or an fma and a product): within 2^-9 of the exact value.  The ends of
+//   the interval are evaluated here from hardware reciprocals (one unit in the last place off), a product and an fma:
+//   within 2^-9 as well.  So every tap's t lies within 2^-8 of [t_lo, t_hi] as computed here, and its floor between
+//   floor(t_lo - 2^-7) and floor(t_hi + 2^-7).
 // A window narrower than S = 16 << level lies inside one block of that level (see RANGE_CELL); its range
 // against cur_min / cur_max decides.  Tiles with a non-finite position or disk radius among their pixels, distances
 // outside the range where the kernel's own skip is valid (2^-96 <= |fragToLight|^2 <= 2^96), or windows too wide,
@@ -929,13 +932,13 @@ __global__ __launch_bounds__(256) void light_classes_kernel(const ShadeParams p,
                         float u_lo = axis == 0 ? c_lo[0] : (axis == 1 ? c_lo[1] : c_lo[2]);
                         float u_hi = axis == 0 ? c_hi[0] : (axis == 1 ? c_hi[1] : c_hi[2]);
                         if (sign < 0.0f) { const float t = u_lo; u_lo = -u_hi; u_hi = -t; }
-                        // a tap on this face has |u| <= |major|: beyond +-1 (plus a rounding, absorbed by the 2 texels) lie only
+                        // a tap on this face has |u| <= |major|: beyond +-1 (plus a rounding, absorbed by the margin below) lie only
                         // quotients of candidates that select another face
                         const float q_lo = __builtin_fmaxf(__builtin_fminf(u_lo * r_small, u_lo * r_large), -1.0f);
                         const float q_hi = __builtin_fminf(__builtin_fmaxf(u_hi * r_small, u_hi * r_large), 1.0f);
                         const float t_lo = fma_(q_lo, half, half), t_hi = fma_(q_hi, half, half);
-                        first = max((int)__builtin_floorf(t_lo) - 2, 0);
-                        last = min((int)__builtin_floorf(t_hi) + 2, p.cube_res - 1);
+                        first = max((int)__builtin_floorf(t_lo - 0x1p-7f), 0);
+                        last = min((int)__builtin_floorf(t_hi + 0x1p-7f), p.cube_res - 1);
                     };
                     int i0, i1, j0, j1;
                     window(su_axis, su_sign, i0, i1);

@@ -66,7 +66,9 @@ class DeviceFrame:
     coverage: torch.Tensor | None = None  # masks from light_coverage(); None: every light covers every pixel
     coverage_flags: torch.Tensor | None = None  # per-light "covers every pixel" words of the same light_coverage() call
     cube_ranges: torch.Tensor | None = None  # cube_shadow_ranges(cube_shadow, cube_layout), or None: every tap is read
-    shade_workspace: torch.Tensor | None = None  # made by shade() on first use: the per-tile light classes
+    # the per-tile light classes, written by every shade() of a frame with cube_ranges: made on first use; two shade()
+    # calls that may overlap on the device (frames in flight on different streams) need a workspace each
+    shade_workspace: torch.Tensor | None = None
 
     @staticmethod
     def upload(f: FrameInputs, device, tiled: bool | None = None, ranges: bool = True) -> "DeviceFrame":
@@ -237,6 +239,11 @@ def cube_shadow_ranges(cubes: torch.Tensor, layout: int, out: torch.Tensor | Non
 def _scene_struct(scene: np.ndarray) -> _lib.SceneInfo:
     assert scene.dtype == SCENE_DTYPE
     return _lib.SceneInfo.from_buffer_copy(scene.tobytes())
+
+
+def shade_workspace_bytes(width: int, rows: int, n_lights: int) -> int:
+    """Size of DeviceFrame.shade_workspace for a strip of this shape."""
+    return int(_lib.load().vkr_shade_workspace_bytes(width, rows, n_lights))
 
 
 def shade(f: DeviceFrame, out_color: torch.Tensor, out_threshold: torch.Tensor) -> None:

@@ -211,6 +211,14 @@ class StripRenderer:
         # rows [top, bottom) reach no halo row: they run while the halo rows are in flight
         top = 0 if p.is_top else HALO
         bottom = r if p.is_bottom else r - HALO
+        if getattr(frame, "cube_ranges", None) is not None and frame.n_lights > 0:
+            # the composition pass writes its per-tile light classes into a workspace: one per set of targets, so that
+            # frames in flight on different streams do not share it
+            slot = self._slots[self._slot]
+            need = be.P.shade_workspace_bytes(frame.width, frame.rows, frame.n_lights)
+            if slot.get("shade_workspace") is None or slot["shade_workspace"].numel() < need:
+                slot["shade_workspace"] = be.empty((need,), torch.uint8)
+            frame = dataclasses.replace(frame, shade_workspace=slot["shade_workspace"])
         self._mark("frame_start")
         be.shade(frame, self.color, self.threshold)
         self._mark("shade")
