@@ -423,7 +423,8 @@ VKR_DEV bool tile_of_block(unsigned b, int tiles_x, int tiles_y, int &tx, int &t
 // MASKED: each light's draw touches only the pixels its light volume covers (one 64-bit mask per
 // light and tile, bit = lane); a light that covers none of the wave's pixels is skipped whole.
 // LAYOUT: VKR_CUBE_LAYOUT_* of the point-shadow cubes.
-template <int LAYOUT, bool POW2, bool MASKED>
+// CLASSES: the per-tile light classes of light_classes_kernel are read (p.light_classes).
+template <int LAYOUT, bool POW2, bool MASKED, bool CLASSES>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void shade_kernel(const ShadeParams p)
 {
     constexpr bool TILED = LAYOUT != VKR_CUBE_LAYOUT_LINEAR, X25 = LAYOUT == VKR_CUBE_LAYOUT_TILED_8X4_X25;
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         typedef const __attribute__((address_space(4))) unsigned long long cmask;
         cmask *cover_c = (cmask *)p.coverage;
         const size_t tiles = (size_t)p.tiles_x * p.tiles_y, tile = (size_t)tile_y * p.tiles_x + tile_x;
-        cmask *classes_c = p.light_classes ? (cmask *)p.light_classes + tile * (size_t)(p.class_words * 2) : nullptr;
+        cmask *classes_c = CLASSES ? (cmask *)p.light_classes + tile * (size_t)(p.class_words * 2) : nullptr;
         // The light loop, with or without the per-light masks.  A kernel built for masks holds both forms: when the
         // coverage pass found that every light covers every pixel (the reference's own light radii, with the camera
         // inside every volume) its waves take the form without masks, which costs neither the mask loads nor the
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                 lp_next = mk3(lf[16], lf[17], lf[18]);
                 lc_next = mk3(lf[20], lf[21], lf[22]);
             }
-            if (classes_c) {
+            if (CLASSES) {
                 if (li == p.light_begin || (li & 63) == 0) {
                     skip_word = classes_c[(li >> 6) * 2];
                     lit_word = classes_c[(li >> 6) * 2 + 1];
@@ -1077,11 +1078,11 @@ extern "C" int32_t vkr_shade(const VkrShadeArgs *a, void *stream)
     const bool pow2 = a->n_lights > 0 && (a->cube_res & (a->cube_res - 1)) == 0;
     const bool masked = p.coverage != nullptr;
     typedef void (*kernel_t)(const ShadeParams);
-    static const kernel_t kernels[12] = {
-        shade_kernel<0, false, false>, shade_kernel<0, false, true>, shade_kernel<0, true, false>, shade_kernel<0, true, true>,
-        shade_kernel<1, false, false>, shade_kernel<1, false, true>, shade_kernel<1, true, false>, shade_kernel<1, true, true>,
-        shade_kernel<2, false, false>, shade_kernel<2, false, true>, shade_kernel<2, true, false>, shade_kernel<2, true, true>};
-    const kernel_t kernel = kernels[a->cube_layout * 4 + (pow2 ? 2 : 0) + (masked ? 1 : 0)];
+#define VKR_SHADE_FORMS(L, C) shade_kernel<L, false, false, C>, shade_kernel<L, false, true, C>, shade_kernel<L, true, false, C>, shade_kernel<L, true, true, C>
+    static const kernel_t kernels[24] = {VKR_SHADE_FORMS(0, false), VKR_SHADE_FORMS(1, false), VKR_SHADE_FORMS(2, false),
+                                         VKR_SHADE_FORMS(0, true), VKR_SHADE_FORMS(1, true), VKR_SHADE_FORMS(2, true)};
+#undef VKR_SHADE_FORMS
+    const kernel_t kernel = kernels[(p.light_classes ? 12 : 0) + a->cube_layout * 4 + (pow2 ? 2 : 0) + (masked ? 1 : 0)];
     // Many lights are drawn in several launches of `chunk` lights each: the waves of a launch drift apart as they
     // skip different lights, and with them the shadow cubes the resident waves of an XCD read from drift apart too,
     // until that XCD's L2 no longer holds them.  A cut costs a re-read of the G-buffer and the targets (48 bytes per
