@@ -106,6 +106,9 @@ public sealed unsafe class HipRenderer : IDisposable
     // VKR_ABI_VERSION of the vkr_hip.h these declarations were written against: a library of another revision
     // would misread the structs passed below
     public const int AbiVersion = 4;
+    // VkrConfig.Flags: 1 = store through an _SRGB target; depth ranges of the point-shadow cubes in the composition pass
+    // (default: frames with at least 16 point lights use them; the image is the same either way)
+    public const int PostSrgbTarget = 1, ShadowRangesAlways = 0x100, ShadowRangesNever = 0x200;
 
     public HipRenderer(in VkrConfig config)
     {

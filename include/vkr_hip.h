@@ -404,6 +404,12 @@ typedef struct vkr_ctx vkr_ctx;
 
 /* The reference's compile-time constants (VulkanRenderer.cs:60-76,1274,1300,1323,1348) as
  * run-time parameters.  Zero in any size field selects the reference's value. */
+/* Depth ranges of the point-shadow cubes in the composition pass (vkr_cube_shadow_ranges, VkrShadeArgs.workspace): by
+ * default a frame with at least VKR_SHADOW_RANGES_MIN_LIGHTS point lights builds and uses them (with few lights the
+ * pass that sorts the lights per tile costs more than the taps it saves); the flags force them on or off. */
+#define VKR_SHADOW_RANGES_ALWAYS 0x100
+#define VKR_SHADOW_RANGES_NEVER 0x200
+#define VKR_SHADOW_RANGES_MIN_LIGHTS 16
 typedef struct VkrConfig {
     int32_t device;            /* HIP device ordinal */
     int32_t width, height;     /* frame size            (reference: 1920 x 1080, Program.cs:48) */
@@ -416,7 +422,7 @@ typedef struct VkrConfig {
     int32_t prefilter_mips;    /* (5) */
     int32_t brdf_lut_res;      /* (512) */
     int32_t frames_in_flight;  /* MaxFramesInFlight     (2) */
-    int32_t flags;             /* VKR_POST_* */
+    int32_t flags;             /* VKR_POST_* | VKR_SHADOW_RANGES_* */
     int32_t frame_rows, row0;  /* the context renders rows [row0, row0 + height) of a frame of frame_rows rows
                                   (see "Strips" below); 0, 0: the whole frame */
 } VkrConfig;

@@ -63,6 +63,7 @@ def test_ranges_are_the_extremes_of_their_blocks(gpu, res, layout):
 
 
 def _shade(P, torch, frame, gpu):
+    frame.tile_classes = True   # also with the few lights of these frames
     color = torch.empty((frame.rows, frame.width, 4), dtype=torch.float16, device=gpu)
     thr = torch.empty_like(color)
     P.shade(frame, color, thr)
@@ -152,3 +153,51 @@ def test_tile_classes_settle_whole_tiles_and_change_nothing(gpu, oracle):
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
     without = _shade(P, torch, dataclasses.replace(d, cube_ranges=None), gpu)
     assert np.array_equal(got[0], without[0]) and np.array_equal(got[1], without[1])
+
+
+@pytest.mark.parametrize("nl,shadow_ranges", [(5, True), (20, None), (5, False)])
+def test_renderer_keeps_its_ranges_current(gpu, oracle, nl, shadow_ranges):
+    """Layer 2: the renderer builds the ranges itself (always / from 16 lights on / never, by VkrConfig.flags) and
+    rebuilds them when a cube is uploaded or the shadow pass runs; every frame equals the oracle's."""
+    from vulkanrenderer_amd.renderer import HipRenderer
+    w, h = 136, 80
+    f = synth.make_frame(71, w, h, nl, 64, 64, irr_res=8, pref_res=16, lut_res=32)
+    other = _blocky_cubes(np.random.default_rng(9), nl, 64)
+    slab = synth.make_scene_mesh(12)
+    with HipRenderer(w, h, max_lights=24, dir_shadow_res=64, point_shadow_res=64, env_res=16, irradiance_res=8, prefilter_res=16,
+                     prefilter_mips=1, brdf_lut_res=32, shadow_ranges=shadow_ranges) as r:
+        env = synth.make_env_cube(np.random.default_rng(2), 16)
+        r.UploadEnvironmentCubemap(env)
+        r.CreateIrradianceCubemap(); r.CreatePrefilteredCubemap(); r.CreateBRDFLUTTexture()
+        f.irradiance, f.prefilter, f.brdf_lut = r.Read(_lib.TARGET_IRRADIANCE), r.Read(_lib.TARGET_PREFILTER, mip=0), r.Read(_lib.TARGET_BRDF_LUT)
+        sky = oracle.skybox(env, f.scene, w, h)
+        mesh = r.CreateMesh(*slab)
+
+        def frame_equals(cubes, draw=False):
+            g = dataclasses.replace(f, cube_shadow=cubes)
+            if draw:
+                sd = [(slab[0], slab[1], np.eye(4))]
+                g.cube_shadow = oracle.point_shadow_maps(sd, f.lights, 64)
+                g.dir_shadow = oracle.dir_shadow_map(sd, f.scene["light_space_matrix"], 64)
+            want_c, want_t = oracle.shade(g, sky)
+            frame = r.CurrentFrame
+            r.UpdateSceneInfo(f.scene)
+            r.UploadGBuffer(f.albedo, f.normal, f.arm, f.position)
+            r.SetLightInfos(f.lights)
+            if not draw:
+                r.UploadDirectionalShadowMap(f.dir_shadow)
+                for i in range(nl):
+                    r.UploadPointShadowMap(i, cubes[i])
+            r.BeginFrame()
+            if draw:
+                r.DrawModel(mesh, np.eye(4))
+            r._call(r._lib.vkr_end_frame)
+            assert np.array_equal(r.Read(_lib.TARGET_COLOR, frame), want_c)
+            assert np.array_equal(r.Read(_lib.TARGET_THRESHOLD, frame), want_t)
+
+        frame_equals(f.cube_shadow)
+        frame_equals(f.cube_shadow)      # the other frame in flight
+        frame_equals(other)              # new cubes in a slot whose ranges were built for the old ones
+        frame_equals(other)
+        frame_equals(None, draw=True)    # the shadow pass overwrites the cubes
+        frame_equals(f.cube_shadow)

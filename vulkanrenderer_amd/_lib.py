@@ -21,6 +21,7 @@ ENV_LAYOUT_LINEAR, ENV_LAYOUT_TILED_4X4, ENV_LAYOUT_FOOTPRINT_TILES = 0, 1, 2
 WRAP_REPEAT, WRAP_CLAMP = 0, 1
 SRC_RGBA8_SRGB, SRC_RGBA16F = 0, 1
 POST_SRGB_TARGET = 1
+SHADOW_RANGES_ALWAYS, SHADOW_RANGES_NEVER, SHADOW_RANGES_MIN_LIGHTS = 0x100, 0x200, 16
 GBUFFER_STATIC_MAX_PIXELS, GBUFFER_STATIC_MAX_DRAWS = 2097152, 64
 IRRADIANCE_SEQUENTIAL, IRRADIANCE_PHI_SLICES, IRRADIANCE_BY_REGION, IRRADIANCE_BY_REGION_ROWS = 0, 1, 2, 3
 IRRADIANCE_FASTEST = -1

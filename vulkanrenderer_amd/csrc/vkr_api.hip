@@ -240,9 +240,13 @@ static int32_t fill_shade_args(vkr_ctx *c, Frame &f, VkrShadeArgs &a)
 
 // The composition pass proper: the depth ranges of the point-shadow cubes are rebuilt first when the cubes changed
 // since they were last built (a shadow pass ran, a cube was uploaded or cleared) or more lights are in use.
-static int32_t shade(vkr_ctx *c, Frame &f, const VkrShadeArgs &a)
+static int32_t shade(vkr_ctx *c, Frame &f, VkrShadeArgs &a)
 {
-    if (f.ranges_lights < f.n_lights) {
+    const bool ranges = !(c->cfg.flags & VKR_SHADOW_RANGES_NEVER) && f.n_lights > 0 &&
+                        ((c->cfg.flags & VKR_SHADOW_RANGES_ALWAYS) || f.n_lights >= VKR_SHADOW_RANGES_MIN_LIGHTS);
+    if (!ranges) {
+        a.cube_ranges = nullptr; a.workspace = nullptr; a.workspace_bytes = 0;
+    } else if (f.ranges_lights < f.n_lights) {
         const int32_t rc = vkr_cube_shadow_ranges(f.cube_shadow, f.n_lights, a.cube_res, a.cube_layout, f.cube_ranges, c->stream);
         if (rc != VKR_OK) return rc;
         f.ranges_lights = f.n_lights;

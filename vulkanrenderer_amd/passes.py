@@ -69,6 +69,9 @@ class DeviceFrame:
     # the per-tile light classes, written by every shade() of a frame with cube_ranges: made on first use; two shade()
     # calls that may overlap on the device (frames in flight on different streams) need a workspace each
     shade_workspace: torch.Tensor | None = None
+    # whether shade() sorts the lights per tile by the ranges first: None = when there are at least
+    # _lib.SHADOW_RANGES_MIN_LIGHTS lights (with few, the sorting pass costs more than the taps it saves)
+    tile_classes: bool | None = None
 
     @staticmethod
     def upload(f: FrameInputs, device, tiled: bool | None = None, ranges: bool = True) -> "DeviceFrame":
@@ -261,7 +264,8 @@ def shade(f: DeviceFrame, out_color: torch.Tensor, out_threshold: torch.Tensor) 
     a.dir_shadow, a.dir_res = _ptr(f.dir_shadow), f.dir_shadow.shape[-1]
     a.cube_shadow, a.cube_res, a.cube_layout = _ptr(f.cube_shadow), f.cube_shadow.shape[-1], f.cube_layout
     a.cube_ranges = _ptr(f.cube_ranges)
-    if f.cube_ranges is not None and f.n_lights > 0:
+    classes = f.n_lights >= _lib.SHADOW_RANGES_MIN_LIGHTS if f.tile_classes is None else f.tile_classes
+    if f.cube_ranges is not None and f.n_lights > 0 and classes:
         need = lib.vkr_shade_workspace_bytes(f.width, f.rows, f.n_lights)
         if f.shade_workspace is None or f.shade_workspace.numel() < need:
             f.shade_workspace = torch.empty(need, dtype=torch.uint8, device=f.albedo.device)

@@ -60,15 +60,19 @@ class HipRenderer:
     def __init__(self, width: int = 1920, height: int = 1080, *, device: int = 0, max_lights: int = 0,
                  dir_shadow_res: int = 0, point_shadow_res: int = 0, env_res: int = 0, irradiance_res: int = 0,
                  prefilter_res: int = 0, prefilter_mips: int = 0, brdf_lut_res: int = 0, srgb_target: bool = False,
-                 frame_rows: int = 0, row0: int = 0):
+                 frame_rows: int = 0, row0: int = 0, shadow_ranges: bool | None = None):
         """`frame_rows` / `row0`: the renderer owns rows [row0, row0 + height) of a frame of frame_rows rows (one
-        strip of a frame rendered on several GPUs: StripShade / strip_exchange / StripFinish end its frames)."""
+        strip of a frame rendered on several GPUs: StripShade / strip_exchange / StripFinish end its frames).
+        `shadow_ranges`: the depth ranges of the point-shadow cubes in the composition pass -- None: used by frames with
+        at least 16 point lights, True / False: always / never (the image is the same)."""
         self._lib = _lib.load()
         cfg = _lib.Config(device=device, width=width, height=height, max_lights=max_lights,
                           dir_shadow_res=dir_shadow_res, point_shadow_res=point_shadow_res, env_res=env_res,
                           irradiance_res=irradiance_res, prefilter_res=prefilter_res, prefilter_mips=prefilter_mips,
                           brdf_lut_res=brdf_lut_res, frames_in_flight=self.MaxFramesInFlight,
-                          flags=_lib.POST_SRGB_TARGET if srgb_target else 0, frame_rows=frame_rows, row0=row0)
+                          flags=(_lib.POST_SRGB_TARGET if srgb_target else 0) |
+                                {None: 0, True: _lib.SHADOW_RANGES_ALWAYS, False: _lib.SHADOW_RANGES_NEVER}[shadow_ranges],
+                          frame_rows=frame_rows, row0=row0)
         self._ctx = C.c_void_p()
         _lib.check(self._lib.vkr_create(C.byref(cfg), C.byref(self._ctx)))
         self.width, self.height = width, height
