@@ -1001,8 +1001,9 @@ def main() -> None:
     flops = (OPS_PER_PIXEL + OPS_PER_PIXEL_LIGHT * args.lights) * shaded_px
     shade_tflops = flops / (kernel_ms["shade"] * 1e-3) / 1e12
     ctr = measured_counters(WIDTH, plan.rows, args.lights, args.cube_res, args.dir_res)
+    uses_classes = dev_frame.cube_ranges is not None and args.lights >= _lib.SHADOW_RANGES_MIN_LIGHTS  # passes.shade's default
     shade_ctr = ctr.get("shade_kernel", {})
-    roofline = {"bound": "valu", "kernel": "shade_kernel" + (" (+ light_classes_kernel)" if dev_frame.cube_ranges is not None else ""), "achieved": round(shade_tflops, 3), "peak": PEAK_FP32_TFLOPS,
+    roofline = {"bound": "valu", "kernel": "shade_kernel" + (" (+ light_classes_kernel)" if uses_classes else ""), "achieved": round(shade_tflops, 3), "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(shade_tflops / PEAK_FP32_TFLOPS, 4), "traffic": shade_ctr.get("traffic_bytes"),
                 "traffic_source": f"{COUNTER_FILE}: separate rocprofv3 --pmc passes of this command, (2 x FETCH_SIZE + WRITE_SIZE) x 1024, not read in this run" if shade_ctr else None,
                 "algorithmic": f"({OPS_PER_PIXEL} + {OPS_PER_PIXEL_LIGHT} x {args.lights}) canonical FP32 ops x {shaded_px} shaded pixels per launch "
@@ -1052,7 +1053,7 @@ def main() -> None:
                                "composition + bloom x2 + ACES/gamma" + ("; halo exchange and RGBA8 gather on rank 0 inside the timed region" if world > 1 else ""),
                    "parallelism": f"strips{world}",
                    "storage": "RGBA16F G-buffer and targets, RGBA8 output, D32F shadow cubes in 8x4-texel tiles holding 25 x depth (the product light.frag forms per tap)"
-                              + ("" if dev_frame.cube_ranges is None else ", with their depth ranges beside them")},
+                              + (", with their depth ranges beside them" if uses_classes else "")},
         "distributed": {"backend": backend if world > 1 else None, "world": world,
                         "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if world > 1 and backend == "nccl" else None,
                         "devices": torch.cuda.device_count()},
@@ -1070,7 +1071,7 @@ def main() -> None:
         if not args.no_ibl:
             out["predicted_ibl_precompute_sharded"] = predict_ibl_sharded((1, 2, 4, 8) if world == 1 else (1, world), device)
     out.update(extra)
-    if dev_frame.cube_ranges is not None:
+    if uses_classes:
         sr = time_shadow_ranges(dev_frame, renderer, compare=not args.no_ranges_compare)
         sr["shade_ms"] = round(kernel_ms["shade"], 4)  # light_classes_kernel + shade_kernel, as timed for the roofline record
         sr["note"] = ("build_ms is not part of a step: the ranges are built when the cubes change, as the cubes themselves are inputs of a step; "
