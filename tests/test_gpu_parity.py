@@ -355,6 +355,23 @@ def test_prefilter_bit_exact(gpu, oracle, rough):
     assert_bits_equal(P.f16_bits(out), want, f"prefilter roughness {rough}")
 
 
+@pytest.mark.parametrize("n,footprints", [(7, False), (12, True), (110, True)])
+def test_prefilter_at_roughness_zero(gpu, oracle, n, footprints):
+    """Roughness 0: the kernel evaluates the samples whose half vector is exactly N once per texel and only the other 137 one by
+    one, then adds all 1024 terms in sample order.  Odd face sizes have texels with a zero component of N, which take the general
+    path; 110^2 faces are a launch of sixteen texels per workgroup."""
+    torch, P = _torch(), _passes()
+    env = synth.make_env_cube(np.random.default_rng(21), 24)
+    want = oracle.prefilter(env, n, 0.0)
+    out = torch.empty((6, n, n, 4), dtype=torch.float16, device=gpu)
+    dev_env = P.to_device_f16(env, gpu)
+    if footprints:
+        P.prefilter(P.tile_env_footprints(dev_env), out, 0.0, env_layout=_lib.ENV_LAYOUT_FOOTPRINT_TILES, env_n=24)
+    else:
+        P.prefilter(dev_env, out, 0.0)
+    assert_bits_equal(P.f16_bits(out), want, f"prefilter {n}^2 at roughness 0")
+
+
 def test_prefilter_large_launch_equals_small_launches(gpu, oracle):
     """A prefilter launch of 65536 texels or more takes sixteen texels per workgroup and the samples in eight passes, a smaller
     one two texels and all samples at once: the whole cube in one launch against the same cube row range by row range,

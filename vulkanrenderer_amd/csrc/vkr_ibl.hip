@@ -962,7 +962,12 @@ template <int LAYOUT, int PREFILTER_TEXELS>
 __global__ __launch_bounds__(256) void prefilter_texel_kernel(const void *env, int env_n, const PrefilterMips mips)
 {
     constexpr int PREFILTER_PASS = 2 * SAMPLE_COUNT / PREFILTER_TEXELS;  // 32 KB of terms either way
-    __shared__ __align__(16) float term[PREFILTER_TEXELS][4][PREFILTER_PASS];  // [0..2] environment colour, [3] N.L
+    // the terms of a pass: [0..2] environment colour, [3] N.L; at roughness 0 the same memory holds the terms of the samples
+    // that need evaluating at all, [sample][texel][4] (see below)
+    constexpr int ODD_MAX = 144;  // 137 at roughness 0
+    constexpr int TERM_FLOATS = PREFILTER_TEXELS * 4 * PREFILTER_PASS > ODD_MAX * PREFILTER_TEXELS * 4 ? PREFILTER_TEXELS * 4 * PREFILTER_PASS : ODD_MAX * PREFILTER_TEXELS * 4;
+    __shared__ __align__(16) float term_store[TERM_FLOATS];
+    float (*const term)[4][PREFILTER_PASS] = (float (*)[4][PREFILTER_PASS])term_store;
     __shared__ __align__(16) float ones[16];
     __shared__ float result[PREFILTER_TEXELS][4];
     const int tid = threadIdx.x;
@@ -994,11 +999,123 @@ __global__ __launch_bounds__(256) void prefilter_texel_kernel(const void *env, i
     __syncthreads();
     // the sixteen summing lanes: texel tid / 4, channel tid % 4 (3: totalWeight += NdotL, as a product with a block of
     // ones that the lane keeps re-reading, so that all sixteen run the same multiply-adds)
-    const int sum_t = (tid >> 2) & (PREFILTER_TEXELS - 1), sum_ch = tid & 3;
+    const int sum_lane = tid;
+    const bool sums = tid < 4 * PREFILTER_TEXELS;  // the first wave, or part of it
+    const int sum_t = (sum_lane >> 2) & (PREFILTER_TEXELS - 1), sum_ch = sum_lane & 3;
     const float4 *const sum_mine = sum_ch == 3 ? (const float4 *)ones : (const float4 *)term[sum_t][sum_ch];
     const float4 *const sum_wts = (const float4 *)term[sum_t][3];
     const int sum_stride = sum_ch == 3 ? 0 : 1;
+    // Roughness 0 (mip 0): the lobe has collapsed onto N.  In binary32 the shader's cos theta = sqrt((1 - y) * (1 / (1 - y)))
+    // comes out as exactly 1 (and sin theta as 0) for 887 of the 1024 samples -- for the other 137 the product rounds to
+    // 1 - 2^-24 and sin theta is 3.45e-4, a different half vector per sample.  A sample with (cos, sin) = (1, 0) has the
+    // half vector N * 1 + (+-0) + (+-0) = N whenever no component of N is zero (a sum with a zero operand is exact), so
+    // all of them share one L, one N.L and one environment colour per texel.  These are computed once, the other samples
+    // are evaluated in one sweep with all their lookups in flight, and the running sums then take their 1024 terms in
+    // sample order from the two sources -- the same terms in the same order as the general path below.
+    __shared__ float same[PREFILTER_TEXELS][4];
+    __shared__ float4 odd_h[ODD_MAX];                    // (hx, hy, hz, sample index) of the samples that need evaluating, in sample order
+    __shared__ unsigned long long odd_mask[SAMPLE_COUNT / 64];  // bit s & 63 of word s >> 6: sample s needs evaluating
+    __shared__ int shared_ok;
+    auto evaluate = [&](int t, float hx, float hy, float hz, float &r, float &g, float &b, float &w) {  // one sample of texel t
+        const float *fr = frame[t];
+        const f3 N = mk3(fr[0], fr[1], fr[2]), tangent = mk3(fr[3], fr[4], fr[5]), bitangent = mk3(fr[6], fr[7], fr[8]);
+        const f3 H = normalize3_fast(mk3(fma_(N.x, hz, fma_(bitangent.x, hy, tangent.x * hx)),
+                                         fma_(N.y, hz, fma_(bitangent.y, hy, tangent.y * hx)),
+                                         fma_(N.z, hz, fma_(bitangent.z, hy, tangent.z * hx))));
+        const float vh2 = 2.0f * dot3(N, H);  // V = N
+        const f3 L = normalize3_fast(mk3(fma_(vh2, H.x, -N.x), fma_(vh2, H.y, -N.y), fma_(vh2, H.z, -N.z)));
+        const float NdotL = max0(dot3(N, L));
+        f3 c = mk3(0.0f, 0.0f, 0.0f);
+        if (NdotL > 0.0f)  // the shader's mip level is clamped to 0 by the sampler
+            c = LAYOUT == VKR_ENV_LAYOUT_FOOTPRINT_TILES ? texcube_rgb_linear_footprint_tiles((const char *)env, env_n, tiles_per_side, L)
+                                                         : texcube_rgb_linear<LAYOUT == VKR_ENV_LAYOUT_TILED_4X4>(env, env_n, L);
+        r = c.x; g = c.y; b = c.z; w = NdotL;
+    };
     float acc = 0.0f;
+    bool summed = false;
+    if (rough == 0.0f) {  // the same for the whole workgroup
+        static_assert(SAMPLE_COUNT == 1024, "four samples per lane below");
+        if (tid == 0) shared_ok = 1;
+        __syncthreads();
+        bool odd[4];
+        float2 tcs4[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {  // sample m * 256 + tid: a wave holds 64 consecutive samples, one word of the mask
+            tcs4[m] = ggx_theta(m * 256 + tid, rough);
+            odd[m] = !(tcs4[m].x == 1.0f && tcs4[m].y == 0.0f);
+            const unsigned long long word = __builtin_amdgcn_ballot_w64(odd[m]);
+            if ((tid & 63) == 0) odd_mask[m * 4 + (tid >> 6)] = word;
+        }
+        if (tid < PREFILTER_TEXELS) {
+            const float *fr = frame[tid];
+            if (fr[0] == 0.0f || fr[1] == 0.0f || fr[2] == 0.0f) shared_ok = 0;  // a zero component: the signs of the zeros could matter
+            evaluate(tid, 0.0f, 0.0f, 1.0f, same[tid][0], same[tid][1], same[tid][2], same[tid][3]);
+        }
+        __syncthreads();
+        int n_odd = 0;
+        for (int k = 0; k < SAMPLE_COUNT / 64; k++) n_odd += __builtin_popcountll(odd_mask[k]);
+        if (shared_ok != 0 && n_odd <= ODD_MAX) {
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+                if (odd[m]) {
+                    const int s = m * 256 + tid, word = s >> 6;
+                    int rank = __builtin_popcountll(odd_mask[word] & ((1ull << (s & 63)) - 1ull));
+                    for (int k = 0; k < word; k++) rank += __builtin_popcountll(odd_mask[k]);
+                    const float2 pcs = g_hammersley_cs[s];
+                    odd_h[rank] = make_float4(pcs.x * tcs4[m].y, pcs.y * tcs4[m].y, tcs4[m].x, __int_as_float(s));
+                }
+            __syncthreads();
+            float (*const odd_term)[PREFILTER_TEXELS][4] = (float (*)[PREFILTER_TEXELS][4])term_store;
+            // three items per trip, so that their environment lookups are in flight together
+#pragma unroll 1
+            for (int item = tid; item < n_odd * PREFILTER_TEXELS; item += 3 * 256) {
+                float r[3], g[3], b[3], w[3];
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    const int it = min(item + u * 256, n_odd * PREFILTER_TEXELS - 1);  // past the end: the last item again, stored once
+                    const float4 h = odd_h[it / PREFILTER_TEXELS];
+                    evaluate(it % PREFILTER_TEXELS, h.x, h.y, h.z, r[u], g[u], b[u], w[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    const int it = item + u * 256;
+                    if (it < n_odd * PREFILTER_TEXELS) {
+                        float *o = odd_term[it / PREFILTER_TEXELS][it % PREFILTER_TEXELS];
+                        o[0] = r[u]; o[1] = g[u]; o[2] = b[u]; o[3] = w[u];
+                    }
+                }
+            }
+            __syncthreads();
+            if (sums) {
+                // One dependent fma per sample, as below; channel 3 adds N.L * 1.  Between two samples that were evaluated lies
+                // a run of shared terms: the same fma over and over, with nothing to load and a scalar trip count.
+                const float c_same = sum_ch == 3 ? 1.0f : same[sum_t][sum_ch], w_same = same[sum_t][3];
+                int done = 0;  // samples added so far
+                float c_next = 0.0f, w_next = 0.0f;
+                if (n_odd > 0) { c_next = sum_ch == 3 ? 1.0f : odd_term[0][sum_t][sum_ch]; w_next = odd_term[0][sum_t][3]; }
+                int upto_next = n_odd > 0 ? __float_as_int(odd_h[0].w) : SAMPLE_COUNT;  // index of the next evaluated sample
+                for (int k = 0; k <= n_odd; k++) {
+                    const int upto = __builtin_amdgcn_readfirstlane(upto_next);
+                    const float c = c_next, w = w_next;
+                    // the terms and the index after these are fetched while this run is added
+                    if (k + 1 < n_odd) { c_next = sum_ch == 3 ? 1.0f : odd_term[k + 1][sum_t][sum_ch]; w_next = odd_term[k + 1][sum_t][3]; upto_next = __float_as_int(odd_h[k + 1].w); }
+                    else upto_next = SAMPLE_COUNT;
+                    int run = __builtin_amdgcn_readfirstlane(upto - done);
+                    // straight-line code for the run: a taken branch costs several fmas, and the runs are short (6.5 on average)
+#define VKR_SAME acc = fma_(c_same, w_same, acc);
+                    for (; run >= 8; run -= 8) { VKR_SAME VKR_SAME VKR_SAME VKR_SAME VKR_SAME VKR_SAME VKR_SAME VKR_SAME }
+                    if (run & 4) { VKR_SAME VKR_SAME VKR_SAME VKR_SAME }
+                    if (run & 2) { VKR_SAME VKR_SAME }
+                    if (run & 1) { VKR_SAME }
+#undef VKR_SAME
+                    if (k < n_odd) acc = fma_(c, w, acc);
+                    done = upto + 1;
+                }
+            }
+            summed = true;
+        }
+    }
+    if (!summed)
     for (int half = 0; half < SAMPLE_COUNT / PREFILTER_PASS; half++) {
         if (half) __syncthreads();  // the sums of the first half have been taken
         // a pass of 256 samples or more: every lane takes all texels of its samples; a shorter one: the lanes share the
@@ -1029,7 +1146,7 @@ __global__ __launch_bounds__(256) void prefilter_texel_kernel(const void *env, i
             }
         }
         __syncthreads();
-        if (tid < 4 * PREFILTER_TEXELS) {
+        if (sums) {
             // The running sum is one dependent fma per sample; the terms are read sixteen samples ahead, so that a step
             // costs the fma's latency and not an LDS round trip.  A sample the shader skips (N.L <= 0) was stored as
             // colour 0, weight 0: adding 0 * 0 leaves the running sum's bits unchanged, so no test is needed here.
@@ -1055,7 +1172,7 @@ __global__ __launch_bounds__(256) void prefilter_texel_kernel(const void *env, i
             }
         }
     }
-    if (tid < 4 * PREFILTER_TEXELS) result[sum_t][sum_ch] = acc;
+    if (sums) result[sum_t][sum_ch] = acc;
     __syncthreads();
     if (tid < PREFILTER_TEXELS && first + tid < n_texels) {
         const int texel = first + tid;
