@@ -908,6 +908,8 @@ __global__ __launch_bounds__(256) void light_classes_kernel(const ShadeParams p,
             }
             bool decided = in_domain && possible != 0u;  // until a face says otherwise
             float nearest = inf, farthest = -inf;        // over the ranges of every face a tap can fall on
+            int faces_seen = 0, one_face = 0, one_i0 = 0, one_i1 = 0, one_j0 = 0, one_j1 = 0;  // the window of a tile that has one face only
+            unsigned one_level = 0u;
             // One face in most tiles, two along a cube edge, three at a corner: more (a light inside the tile's box) are left
             // to the per-pixel path.  The lanes of a wave are different lights, so the trip count is the wave's largest.
             for (int trip = 0; trip < 3 && wave_any(decided && possible != 0u); trip++) {
@@ -959,11 +961,32 @@ __global__ __launch_bounds__(256) void light_classes_kernel(const ShadeParams p,
                                                        (size_t)((unsigned)j0 >> shift) * p.range_cells + ((unsigned)i0 >> shift)];
                     nearest = __builtin_fminf(nearest, range.x);
                     farthest = __builtin_fmaxf(farthest, range.y);
+                    faces_seen++; one_face = face; one_i0 = i0; one_i1 = i1; one_j0 = j0; one_j1 = j1; one_level = level;
                 }
             }
             decided = decided && possible == 0u;
             skip = decided && cur_min > farthest;
             lit = decided && !(cur_max > nearest);
+            // A second look for a one-face tile that a coarse block left undecided: the blocks of level 0 (32 x 32 texels)
+            // at every other cell cover the cells of the window, up to three by three of them, more closely than one block of
+            // a coarser level does (a window 40 texels wide sat in a block of 128).
+            const unsigned cx0 = (unsigned)one_i0 >> 4, cy0 = (unsigned)one_j0 >> 4;
+            const unsigned nx = ((((unsigned)one_i1 >> 4) - cx0) >> 1) + 1u, ny = ((((unsigned)one_j1 >> 4) - cy0) >> 1) + 1u;
+            const bool again = decided && !skip && !lit && faces_seen == 1 && one_level >= 1u && nx <= 3u && ny <= 3u;
+            if (wave_any(again)) {
+                float lo2 = inf, hi2 = -inf;
+                const float2 *level0 = p.cube_ranges + (((size_t)li * (RANGE_LEVELS + 1)) * 6u + (unsigned)one_face) * ((size_t)p.range_cells * p.range_cells);
+#pragma unroll
+                for (unsigned dy = 0; dy < 3; dy++)
+#pragma unroll
+                    for (unsigned dx = 0; dx < 3; dx++)
+                        if (again && dx < nx && dy < ny) {
+                            const float2 range = level0[(size_t)(cy0 + 2u * dy) * p.range_cells + (cx0 + 2u * dx)];
+                            lo2 = __builtin_fminf(lo2, range.x);
+                            hi2 = __builtin_fmaxf(hi2, range.y);
+                        }
+                if (again) { skip = cur_min > hi2; lit = !(cur_max > lo2); }
+            }
         }
         const unsigned long long skip_mask = __builtin_amdgcn_ballot_w64(skip), lit_mask = __builtin_amdgcn_ballot_w64(lit);
         if (lane == 0) {
