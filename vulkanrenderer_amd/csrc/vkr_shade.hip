@@ -412,6 +412,24 @@ VKR_DEV bool tile_of_block(unsigned b, int tiles_x, int tiles_y, int &tx, int &t
     return true;
 }
 
+VKR_DEV unsigned f16_low_of(float x) { return (unsigned)__builtin_bit_cast(unsigned short, to_f16(x)); }
+// The additive blend of one light draw into an RGBA16F target: target + x formed in binary32 (rounded), then rounded to
+// binary16.  The target is kept as a binary16 value in the low half of a register: a mixed-precision fma reads it as it
+// is (x * 1.0 + target, result in binary32), one conversion follows -- an add and two conversions before.
+// (v_fma_mixlo_f16 would do it in one instruction, but it rounds the exact sum once, which differs from the two roundings
+// in one result out of 10^4.)
+VKR_DEV unsigned blend_f16(unsigned target, float x)
+{
+    float sum;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[0,0,1]" : "=v"(sum) : "v"(x), "v"(target));
+    return f16_low_of(sum);
+}
+
+VKR_DEV uint2 pack4_f16(unsigned r, unsigned g, unsigned b)  // alpha 1.0
+{
+    return make_uint2(__builtin_amdgcn_perm(g, r, 0x05040100u), __builtin_amdgcn_perm(0x3C00u, b, 0x05040100u));
+}
+
 // Five waves per SIMD (96 VGPRs, none spilled).  Measured at 4K / 64 lights with this loop: 5 waves 3.58 ms,
 // 6 waves (80 VGPRs, values reloaded from scratch memory inside the loop) 3.72 ms; an earlier, longer loop
 // measured 4 waves 5.5 ms, 5 waves 4.6, 6 waves 4.5, 7 waves (spills inside the loop) 4.6.
@@ -507,8 +525,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         bool bright = luminance(Lo.x, Lo.y, Lo.z) > 1.0f;
         t0 = bright ? Lo.x : 0.0f; t1 = bright ? Lo.y : 0.0f; t2 = bright ? Lo.z : 0.0f;
     }
-    c0 = round_f16(c0); c1 = round_f16(c1); c2 = round_f16(c2);
-    t0 = round_f16(t0); t1 = round_f16(t1); t2 = round_f16(t2);
+    // from here on the targets are binary16 values in the low halves of these registers (see blend_f16)
+    unsigned h0 = f16_low_of(c0), h1 = f16_low_of(c1), h2 = f16_low_of(c2), g0 = f16_low_of(t0), g1 = f16_low_of(t1), g2 = f16_low_of(t2);
 
     // A cleared G-buffer texel has normal (0,0,0): the light shader's result for it is 0 under
     // IEEE maxNum semantics, so such pixels skip the light loop.
@@ -568,6 +586,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             const float dist2 = dot3(Fv, Fv);
             float dist, inv_dist, att;
             const bool slow_domain = !(dist2 >= 0x1p-96f && dist2 <= 0x1p96f);
+            const unsigned long long slow_lanes = __builtin_amdgcn_ballot_w64(slow_domain);  // taken here: after the branch below it costs a select and a compare
             if (__builtin_expect(slow_domain, 0)) {
                 dist = __builtin_sqrtf(dist2);
                 inv_dist = 1.0f / dist;
@@ -589,7 +608,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             // same zero whatever the taps say (the other factors are finite inside the fast domain, given finite
             // G-buffer values and light colours), and adding it leaves both targets as they are: a wave that
             // faces away from the light is done.  Masks of single comparisons are combined as scalars.
-            unsigned long long live = __builtin_amdgcn_ballot_w64(slow_domain) | __builtin_amdgcn_ballot_w64(NdotL > 0.0f);
+            unsigned long long live = slow_lanes | __builtin_amdgcn_ballot_w64(NdotL > 0.0f);
             if (MASKS) live &= cover_mask;
             if (live == 0ull) { VKR_COUNT(0); continue; }
             const int face0 = tile_lit ? -2 : wave_common_face(Fv.x, Fv.y, Fv.z, disk);
@@ -609,7 +628,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                 count = taps_any_face<TILED, POW2, X25>(cube, p.cube_res, X, Y, Z, cur, axes & 1u, axes & 2u, axes & 4u);
             }
             // all 20 taps in shadow: the factor 1 - 20/20 is an exact zero, same argument
-            if ((live & (__builtin_amdgcn_ballot_w64(slow_domain) | __builtin_amdgcn_ballot_w64(count < 20.0f))) == 0ull) { VKR_COUNT(4); continue; }
+            if ((live & (slow_lanes | __builtin_amdgcn_ballot_w64(count < 20.0f))) == 0ull) { VKR_COUNT(4); continue; }
             VKR_COUNT(5);
             const f3 Hv = add3(V, L);
             const float hlen2 = dot3(Hv, Hv);  // at most about 4: only the lower end of the fast domain needs a test
@@ -632,14 +651,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             const bool over = luminance(o0, o1, o2) > 1.0f;  // light.frag:78-82
             const bool bright = covered && over;
             if (MASKS) {  // an uncovered pixel is not part of this draw: its targets keep their bits
-                c0 = covered ? round_f16(c0 + o0) : c0; c1 = covered ? round_f16(c1 + o1) : c1; c2 = covered ? round_f16(c2 + o2) : c2;
+                h0 = covered ? blend_f16(h0, o0) : h0; h1 = covered ? blend_f16(h1, o1) : h1; h2 = covered ? blend_f16(h2, o2) : h2;
             } else {
-                c0 = round_f16(c0 + o0); c1 = round_f16(c1 + o1); c2 = round_f16(c2 + o2);
+                h0 = blend_f16(h0, o0); h1 = blend_f16(h1, o1); h2 = blend_f16(h2, o2);
             }
             if ((__builtin_amdgcn_ballot_w64(over) & cover_mask) != 0ull) {  // adding 0 to the thresholded target changes nothing
-                t0 = round_f16(t0 + (bright ? o0 : 0.0f));
-                t1 = round_f16(t1 + (bright ? o1 : 0.0f));
-                t2 = round_f16(t2 + (bright ? o2 : 0.0f));
+                g0 = blend_f16(g0, bright ? o0 : 0.0f);
+                g1 = blend_f16(g1, bright ? o1 : 0.0f);
+                g2 = blend_f16(g2, bright ? o2 : 0.0f);
             }
         }
         };
@@ -652,8 +671,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             light_loop(std::false_type{});
         }
     }
-    p.out_color[px] = pack4(c0, c1, c2, 1.0f);
-    p.out_threshold[px] = pack4(t0, t1, t2, 1.0f);
+    p.out_color[px] = pack4_f16(h0, h1, h2);
+    p.out_threshold[px] = pack4_f16(g0, g1, g2);
 }
 
 // Row-major face -> 8x4-texel tiles.  Eight lanes move one tile (16 bytes each); a wave takes eight tiles side by
