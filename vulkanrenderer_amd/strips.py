@@ -60,6 +60,7 @@ class HipBackend:
             raise RuntimeError("the strip renderer needs a GPU: there is no CPU path")
         self.P = passes
         self.device = device
+        self._side = None  # a second stream for the passes that run beside the point-shadow pass
 
     def empty(self, shape, dtype):
         return torch.empty(shape, dtype=dtype, device=self.device)
@@ -84,14 +85,29 @@ class HipBackend:
         `env` = (environment cube tensor, VKR_ENV_LAYOUT_*): the skybox is drawn behind the strip's geometry."""
         import dataclasses
         P = self.P
-        if env is not None:
-            frame = dataclasses.replace(frame, background=P.skybox(env[0], frame.scene, frame.width, frame.rows, frame_rows, row0, env_layout=env[1]))
-        ga, gn, gm, gp = P.gbuffer(draws, frame.scene, frame.width, frame.rows, self.device, frame_rows, row0)
+        # The skybox, the geometry pass and the directional depth map go to a second stream: the point-shadow pass is long
+        # and bound by binary64 arithmetic at half-empty waves, and these passes fit beside it.
+        main = torch.cuda.current_stream(self.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        side = self._side
+        side.wait_stream(main)
         sd = [(d["positions"], d["triangles"], d["model"]) for d in draws]
+        with torch.cuda.stream(side):
+            background = None
+            if env is not None:
+                background = P.skybox(env[0], frame.scene, frame.width, frame.rows, frame_rows, row0, env_layout=env[1])
+            ga, gn, gm, gp = P.gbuffer(draws, frame.scene, frame.width, frame.rows, self.device, frame_rows, row0)
+            dmap = P.dir_shadow_map(sd, frame.scene["light_space_matrix"], dir_res, self.device)
         cubes, layout = P.point_shadow_maps(sd, frame.lights, frame.n_lights, shadow_res)
-        dmap = P.dir_shadow_map(sd, frame.scene["light_space_matrix"], dir_res, self.device)
-        return dataclasses.replace(frame, albedo=ga, normal=gn, arm=gm, position=gp, cube_shadow=cubes, cube_layout=layout, dir_shadow=dmap,
-                                   cube_ranges=P.cube_shadow_ranges(cubes, layout))
+        ranges = P.cube_shadow_ranges(cubes, layout) if frame.n_lights >= _lib.SHADOW_RANGES_MIN_LIGHTS else None
+        main.wait_stream(side)
+        for t in (background, ga, gn, gm, gp, dmap):  # made on the side stream, used and released on this one
+            if t is not None:
+                t.record_stream(main)
+        out = dataclasses.replace(frame, albedo=ga, normal=gn, arm=gm, position=gp, cube_shadow=cubes, cube_layout=layout, dir_shadow=dmap,
+                                  cube_ranges=ranges)
+        return out if background is None else dataclasses.replace(out, background=background)
 
     def with_coverage(self, frame, volume_mesh, frame_rows, row0):
         """The strip's frame with light-volume masks attached; `volume_mesh` = (verts, triangles) device tensors."""
