@@ -359,7 +359,7 @@ def test_prefilter_bit_exact(gpu, oracle, rough):
 def test_prefilter_at_roughness_zero(gpu, oracle, n, footprints):
     """Roughness 0: the kernel evaluates the samples whose half vector is exactly N once per texel and only the other 137 one by
     one, then adds all 1024 terms in sample order.  Odd face sizes have texels with a zero component of N, which take the general
-    path; 110^2 faces are a launch of sixteen texels per workgroup."""
+    path, as do launches of two texels per workgroup (the 7^2 and 12^2 faces here); 110^2 faces are a launch of sixteen texels per workgroup, the form that shares the terms."""
     torch, P = _torch(), _passes()
     env = synth.make_env_cube(np.random.default_rng(21), 24)
     want = oracle.prefilter(env, n, 0.0)

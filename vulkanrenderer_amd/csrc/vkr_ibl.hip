@@ -1033,7 +1033,9 @@ __global__ __launch_bounds__(256) void prefilter_texel_kernel(const void *env, i
     };
     float acc = 0.0f;
     bool summed = false;
-    if (rough == 0.0f) {  // the same for the whole workgroup
+    // (Sixteen texels per workgroup only: with two, the one pass of the general path already spreads the samples over all
+    // lanes and its sums stream from LDS; the sweep-then-sum form measured 0.3 ms slower there.)
+    if (PREFILTER_TEXELS == 16 && rough == 0.0f) {  // the same for the whole workgroup
         static_assert(SAMPLE_COUNT == 1024, "four samples per lane below");
         if (tid == 0) shared_ok = 1;
         __syncthreads();
