@@ -201,3 +201,54 @@ def test_renderer_keeps_its_ranges_current(gpu, oracle, nl, shadow_ranges):
         frame_equals(other)
         frame_equals(None, draw=True)    # the shadow pass overwrites the cubes
         frame_equals(f.cube_shadow)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_tile_classes_on_adversarial_frames(gpu, seed):
+    """Random frames built to sit on the classes' boundaries: lights on, just above and far from the surface, along the
+    directions where the taps change cube face, behind the surface; depth maps whose values straddle the distances of the
+    pixels (smooth, blocky, constant at exactly a pixel's cur, cleared); the kernel with the classes against the kernel
+    that reads every tap."""
+    import torch
+    from vulkanrenderer_amd import passes as P
+    rng = np.random.default_rng(1000 + seed)
+    w, h, nl, res = 96, 64, 40, int(rng.choice([64, 128, 48]))
+    f = synth.make_frame(200 + seed, w, h, nl, res, 64, irr_res=8, pref_res=16, lut_res=32)
+    pos = f.position.view(np.float16).astype(np.float32)[..., :3]
+    lights = f.lights.copy()
+    for i in range(nl):
+        kind = i % 5
+        y, x = rng.integers(0, h), rng.integers(0, w)
+        p = pos[y, x]
+        if kind == 0:    # on the surface, inside a tile's box
+            lights["position"][i] = p
+        elif kind == 1:  # a hair above it
+            lights["position"][i] = p + np.float32([0, 10.0 ** rng.uniform(-4, -1), 0])
+        elif kind == 2:  # so that a pixel's direction runs along a cube edge or corner
+            d = np.float32(rng.choice([-1, 1], 3)) * np.float32([1, 1, rng.choice([0, 1])]) * np.float32(rng.uniform(0.5, 3))
+            lights["position"][i] = p - d
+        elif kind == 3:  # below the surface
+            lights["position"][i] = p - np.float32([0, rng.uniform(0.1, 2), 0])
+        # kind 4: where make_lights put it
+    f.lights = lights
+    style = seed % 4
+    if style == 1:
+        f.cube_shadow = _blocky_cubes(rng, nl, res)
+    elif style == 2:  # constant maps at exactly the comparison value of some pixel: cur == closest in whole tiles
+        c = np.empty((nl, 6, res, res), np.float32)
+        for i in range(nl):
+            y, x = rng.integers(0, h), rng.integers(0, w)
+            dist = np.float32(np.sqrt(np.float32(((pos[y, x] - lights["position"][i]) ** 2).sum())))
+            c[i] = (dist - np.float32(0.15)) / np.float32(25.0)
+        f.cube_shadow = c
+    elif style == 3:
+        f.cube_shadow = np.ones((nl, 6, res, res), np.float32)  # cleared: nothing is in shadow
+    d = P.DeviceFrame.upload(f, gpu, tiled=None if seed % 2 else False)
+    with_classes = _shade(P, torch, d, gpu)
+    plain = dataclasses.replace(d, cube_ranges=None)
+    color = torch.empty((h, w, 4), dtype=torch.float16, device=gpu); thr = torch.empty_like(color)
+    P.shade(plain, color, thr)
+    torch.cuda.synchronize()
+    assert np.array_equal(with_classes[0], P.f16_bits(color)) and np.array_equal(with_classes[1], P.f16_bits(thr))
+    masks = d.shade_workspace.cpu().numpy().view(np.uint64)
+    assert masks.any()  # the classes did decide something
