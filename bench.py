@@ -1030,6 +1030,14 @@ def main() -> None:
     pair_counts = shade_pair_counts(dev_frame, renderer) if args.pair_counts else stored_pair_counts(WIDTH, plan.rows, args.lights, args.cube_res)
     if pair_counts:
         roofline["wave_light_pairs"] = pair_counts
+        # the canonical count again, for the work the kernel still performs: 681 of the 810 operations per pixel and light are
+        # the 20 shadow taps, which only the pairs that read them perform
+        tap_frac = (pair_counts["one_face_taps_read"] + pair_counts["edge_or_corner_taps_read"]) / max(pair_counts["pairs"], 1)
+        performed = (OPS_PER_PIXEL + (OPS_PER_PIXEL_LIGHT - 681 + 681 * tap_frac) * args.lights) * shaded_px
+        roofline["performed_work"] = {"pairs_reading_taps_frac": round(tap_frac, 4), "achieved": round(performed / (kernel_ms["shade"] * 1e-3) / 1e12, 3),
+                                      "frac": round(performed / (kernel_ms["shade"] * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4),
+                                      "note": "canonical operations of the taps counted only for the (wave, light) pairs that read them; what is left is mostly the "
+                                              "Cook-Torrance evaluation, whose canonical operations are close to one issued instruction each (a tap's 34 are about 8)"}
     def hbm_rec(kernel, bytes_per_px, ms, algorithmic, ctr_name):
         gbs = bytes_per_px * strip_px / (ms * 1e-3) / 1e9
         return {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
