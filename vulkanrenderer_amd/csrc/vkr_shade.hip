@@ -585,9 +585,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             const f3 Fv = sub3(pos, lp);
             const float dist2 = dot3(Fv, Fv);
             float dist, inv_dist, att;
-            const bool slow_domain = !(dist2 >= 0x1p-96f && dist2 <= 0x1p96f);
-            const unsigned long long slow_lanes = __builtin_amdgcn_ballot_w64(slow_domain);  // taken here: after the branch below it costs a select and a compare
-            if (__builtin_expect(slow_domain, 0)) {
+            // Lanes outside the domain of the short sequences.  The long and the short forms give the same bits inside
+            // it (both round correctly), so the whole wave takes the long one when any lane needs it: a scalar branch,
+            // no per-lane one.
+            const unsigned long long slow_lanes = __builtin_amdgcn_ballot_w64(!(dist2 >= 0x1p-96f)) | __builtin_amdgcn_ballot_w64(!(dist2 <= 0x1p96f));
+            if (__builtin_expect(slow_lanes != 0ull, 0)) {
                 dist = __builtin_sqrtf(dist2);
                 inv_dist = 1.0f / dist;
                 att = 1.0f / (dist * dist);
@@ -611,29 +613,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             unsigned long long live = slow_lanes | __builtin_amdgcn_ballot_w64(NdotL > 0.0f);
             if (MASKS) live &= cover_mask;
             if (live == 0ull) { VKR_COUNT(0); continue; }
-            const int face0 = tile_lit ? -2 : wave_common_face(Fv.x, Fv.y, Fv.z, disk);
-            float count;
-            if (tile_lit) {
-                VKR_COUNT(7);
-                count = 0.0f;
-            } else if (face0 >= 0) {
-                VKR_COUNT(2);
-                const float *fb = cube + (size_t)face0 * face_stride;
-                if (face0 >= 4) count = taps_one_face<2, TILED, POW2, X25>(fb, p.cube_res, X, Y, Z, cur);
-                else if (face0 >= 2) count = taps_one_face<1, TILED, POW2, X25>(fb, p.cube_res, X, Y, Z, cur);
-                else count = taps_one_face<0, TILED, POW2, X25>(fb, p.cube_res, X, Y, Z, cur);
-            } else {  // the wave straddles a cube edge or corner
-                VKR_COUNT(3);
-                const unsigned axes = wave_major_axes(Fv.x, Fv.y, Fv.z, disk);
-                count = taps_any_face<TILED, POW2, X25>(cube, p.cube_res, X, Y, Z, cur, axes & 1u, axes & 2u, axes & 4u);
-            }
+            // The rest of the draw once the number of taps in shadow is known; LIT: known to be zero for the whole tile.
+            auto finish = [&](auto lit_known, float count) {
+            constexpr bool LIT = decltype(lit_known)::value;
             // all 20 taps in shadow: the factor 1 - 20/20 is an exact zero, same argument
-            if ((live & (slow_lanes | __builtin_amdgcn_ballot_w64(count < 20.0f))) == 0ull) { VKR_COUNT(4); continue; }
+            if (!LIT && (live & (slow_lanes | __builtin_amdgcn_ballot_w64(count < 20.0f))) == 0ull) { VKR_COUNT(4); return; }
             VKR_COUNT(5);
             const f3 Hv = add3(V, L);
             const float hlen2 = dot3(Hv, Hv);  // at most about 4: only the lower end of the fast domain needs a test
             float inv_hlen;
-            if (__builtin_expect(!(hlen2 >= 0x1p-96f), 0)) inv_hlen = 1.0f / __builtin_sqrtf(hlen2);
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(hlen2 >= 0x1p-96f)) != 0ull, 0)) inv_hlen = 1.0f / __builtin_sqrtf(hlen2);  // same bits inside the domain
             else inv_hlen = fast_rcp_rn(fast_sqrt_rn(hlen2));
             const f3 H = scale3(Hv, inv_hlen);
             // the denominators below lie in [1e-4, 8]: well inside fast_rcp_rn's exact domain
@@ -643,7 +632,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             const float isd = fast_rcp_rn(fma_(fourNdotV, NdotL, 0.0001f));
             const float DG = D * G;
 
-            const float lit = 1.0f - count * (1.0f / 20.0f);
+            // no tap in shadow: the factor is 1 - 0 * (1/20) = 1 and x * 1 = x bit for bit, so the three products are left out
+            const float lit = LIT ? 1.0f : 1.0f - count * (1.0f / 20.0f);
 
             const float o0 = ((fma_((1.0f - F.x) * albedo.x, INV_PI, (DG * F.x) * isd) * (lc.x * att)) * lit) * NdotL;
             const float o1 = ((fma_((1.0f - F.y) * albedo.y, INV_PI, (DG * F.y) * isd) * (lc.y * att)) * lit) * NdotL;
@@ -660,6 +650,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                 g1 = blend_f16(g1, bright ? o1 : 0.0f);
                 g2 = blend_f16(g2, bright ? o2 : 0.0f);
             }
+            };
+            if (tile_lit) { VKR_COUNT(7); finish(std::true_type{}, 0.0f); continue; }
+            const int face0 = wave_common_face(Fv.x, Fv.y, Fv.z, disk);
+            float count;
+            if (face0 >= 0) {
+                VKR_COUNT(2);
+                const float *fb = cube + (size_t)face0 * face_stride;
+                if (face0 >= 4) count = taps_one_face<2, TILED, POW2, X25>(fb, p.cube_res, X, Y, Z, cur);
+                else if (face0 >= 2) count = taps_one_face<1, TILED, POW2, X25>(fb, p.cube_res, X, Y, Z, cur);
+                else count = taps_one_face<0, TILED, POW2, X25>(fb, p.cube_res, X, Y, Z, cur);
+            } else {  // the wave straddles a cube edge or corner
+                VKR_COUNT(3);
+                const unsigned axes = wave_major_axes(Fv.x, Fv.y, Fv.z, disk);
+                count = taps_any_face<TILED, POW2, X25>(cube, p.cube_res, X, Y, Z, cur, axes & 1u, axes & 2u, axes & 4u);
+            }
+            finish(std::false_type{}, count);
         }
         };
         if (MASKED) {
