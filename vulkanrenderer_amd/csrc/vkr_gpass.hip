@@ -83,6 +83,7 @@ VKR_DEV void gpass_vertex(const VkrGpassDraw &d, const float *vp, unsigned i, Gp
 
 __global__ __launch_bounds__(256) void gpass_visibility_kernel(const GpassParams p)
 {
+    __shared__ RasterPool pools[4];
     const VkrGpassDraw &d = p.draws[p.draw];
     // Lane -> triangle: neighbours in a mesh are neighbours on the screen and of similar size, so with consecutive
     // triangles per wave the few waves that own the triangles next to the camera would run long after the rest
@@ -103,16 +104,16 @@ __global__ __launch_bounds__(256) void gpass_visibility_kernel(const GpassParams
         }
         STri tr;
         raster_setup(clip, tr);
-        int qy0, qy1, rx0, rx1, ry0, ry1;
+        int ry0, ry1;
         // BACK faces (D > 0) and degenerate triangles are culled
-        have = !clip_reject(clip) && tr.D < 0.0 && shadow_bbox(clip, p.width, bx0, qy0, bx1, qy1) && shadow_bbox(clip, p.frame_rows, rx0, ry0, rx1, ry1);
+        have = !clip_reject(clip) && tr.D < 0.0 && raster_bbox(clip, p.width, p.frame_rows, bx0, ry0, bx1, ry1);
         if (have) {
             by0 = max(ry0 - p.row0, 0); by1 = min(ry1 - p.row0, p.rows - 1);
             have = by0 <= by1;
         }
     }
     const double sx = 2.0 / (double)p.width, sy = 2.0 / (double)p.frame_rows;
-    raster_boxes<true, true>(have, clip, clip, p.tri_base + (unsigned)t, bx0, by0, bx1, by1, [&](const STri &tr, const float (&)[3][4], unsigned id, int x, int y) {
+    raster_boxes<true, true>(pools[threadIdx.x >> 6], have, clip, clip, p.tri_base + (unsigned)t, bx0, by0, bx1, by1, [&](const STri &tr, const float (&)[3][4], unsigned id, int x, int y) {
         const double xn = __builtin_fma((double)x + 0.5, sx, -1.0), yn = __builtin_fma((double)(p.row0 + y) + 0.5, sy, -1.0);
         const double e0 = s_edge(tr, 0, xn, yn), e1 = s_edge(tr, 1, xn, yn), e2 = s_edge(tr, 2, xn, yn);
         if (!(e0 >= 0.0 && e1 >= 0.0 && e2 >= 0.0 && (e0 + e1) + e2 > 0.0)) return;

@@ -48,8 +48,10 @@ VKR_DEV void raster_flip(STri &t)
     t.D = -t.D;
 }
 
-// Conservative texel bounding box of the part of a clip-space triangle with z >= 0 and w > 0.
-VKR_DEV bool shadow_bbox(const float (&c)[3][4], int res, int &bx0, int &by0, int &bx1, int &by1)
+static constexpr double RASTER_SLACK = 1.0 / 1024.0;
+
+// Conservative sample bounding box of the part of a clip-space triangle with z >= 0 and w > 0, on a grid of res_x x res_y samples.
+VKR_DEV bool raster_bbox(const float (&c)[3][4], int res_x, int res_y, int &bx0, int &by0, int &bx1, int &by1)
 {
     double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
     int n = 0;
@@ -75,17 +77,22 @@ VKR_DEV bool shadow_bbox(const float (&c)[3][4], int res, int &bx0, int &by0, in
     }
     if (n == 0) return false;
     if (unbounded) { xmin = ymin = -1e300; xmax = ymax = 1e300; }
-    const double half = 0.5 * (double)res;
-    double fx0 = __builtin_floor((xmin + 1.0) * half - 0.5) - 1.0, fx1 = __builtin_ceil((xmax + 1.0) * half - 0.5) + 1.0;
-    double fy0 = __builtin_floor((ymin + 1.0) * half - 0.5) - 1.0, fy1 = __builtin_ceil((ymax + 1.0) * half - 0.5) + 1.0;
+    // Sample i has its centre at i + 0.5 texels: those with xmin <= centre <= xmax, widened by RASTER_SLACK texels for the
+    // rounding of the corners' positions here and of the edge functions' coefficients (both of the order of 2^-50 of a
+    // face's width, so far less).  A triangle that reaches no sample centre gets an empty box.
+    const double half_x = 0.5 * (double)res_x, half_y = 0.5 * (double)res_y;
+    double fx0 = __builtin_ceil((xmin + 1.0) * half_x - (0.5 + RASTER_SLACK)), fx1 = __builtin_floor((xmax + 1.0) * half_x - (0.5 - RASTER_SLACK));
+    double fy0 = __builtin_ceil((ymin + 1.0) * half_y - (0.5 + RASTER_SLACK)), fy1 = __builtin_floor((ymax + 1.0) * half_y - (0.5 - RASTER_SLACK));
     if (!(fx0 > 0.0)) fx0 = 0.0;
     if (!(fy0 > 0.0)) fy0 = 0.0;
-    if (!(fx1 < (double)(res - 1))) fx1 = (double)(res - 1);
-    if (!(fy1 < (double)(res - 1))) fy1 = (double)(res - 1);
+    if (!(fx1 < (double)(res_x - 1))) fx1 = (double)(res_x - 1);
+    if (!(fy1 < (double)(res_y - 1))) fy1 = (double)(res_y - 1);
     if (fx0 > fx1 || fy0 > fy1) return false;
     bx0 = (int)fx0; by0 = (int)fy0; bx1 = (int)fx1; by1 = (int)fy1;
     return true;
 }
+
+VKR_DEV bool shadow_bbox(const float (&c)[3][4], int res, int &bx0, int &by0, int &bx1, int &by1) { return raster_bbox(c, res, res, bx0, by0, bx1, by1); }
 
 // True when the triangle lies entirely outside one plane of the clip volume (-w <= x,y <= w, z >= 0):
 // nothing of it can be covered, and the binary64 setup can be skipped.  Exact comparisons on the
@@ -104,55 +111,97 @@ VKR_DEV bool clip_reject(const float (&c)[3][4])
 
 VKR_DEV float readlane_f(float x, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src)); }
 
-static constexpr int RASTER_BIG = 128;  // bounding boxes with more samples than this are walked by the whole wave (32..128 measured equal, 1024 40 % slower)
+#ifndef VKR_RASTER_BIG
+#define VKR_RASTER_BIG 16
+#endif
+static constexpr int RASTER_BIG = VKR_RASTER_BIG;  // bounding boxes with more samples than this are walked by the whole wave (0 to 32 measured equal on a scene of boxes of about a hundred samples, 64 25 % slower)
+
+// One wave's share of LDS for raster_boxes: the set-up triangles of the lanes whose boxes the whole wave walks.
+struct alignas(16) RasterRecord {
+    double a[3], b[3], c[3], D, inv_D;
+    float z[3]; unsigned tag;
+    int bx0, by0; unsigned w, samples;
+    float attr[9]; float inv_w;  // the first three components of the three attribute rows; 1 / w rounded
+};
+static_assert(sizeof(RasterRecord) == 160, "ten 16-byte LDS accesses per record");
+struct RasterPool { RasterRecord rec[64]; };
+
+VKR_DEV void raster_wave_fence()
+{
+    // LDS accesses of one wave are carried out in order; the fences keep the compiler from moving them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // Calls pixel(tri, attr, tag, i, j) for every sample (i, j) of the bounding box of each lane's
-// triangle (`have`: the lane has one).  A lane walks a small box itself; a large box is taken over
-// by the whole wave -- its owner's corners are broadcast, every lane redoes the (deterministic)
-// setup and takes every 64th sample -- so one screen-filling triangle does not leave 63 lanes idle.
-// Every lane of the wave must call this (no early returns before it).  FLIP: front faces were kept.
+// triangle (`have`: the lane has one; of attr's fourth components pixel sees zeros).  A lane walks a small box itself;
+// a larger box is taken over by the whole wave, every lane taking every 64th sample, so one large triangle does not
+// leave 63 lanes idle: each such triangle is set up by its own lane (all of them at once), left in the wave's `pool`
+// in LDS, and read from there by all lanes when its turn comes.  (Before, its corners were broadcast and every lane
+// redid the set-up, which cost more than walking a box of a hundred samples.)
+// Every lane of the wave must call this (no early returns before it), with the wave's own pool.  FLIP: front faces were kept.
 template <bool FLIP, bool INV_D, typename F>
-VKR_DEV void raster_boxes(bool have, const float (&clip)[3][4], const float (&attr)[3][4], unsigned tag,
+VKR_DEV void raster_boxes(RasterPool &pool, bool have, const float (&clip)[3][4], const float (&attr)[3][4], unsigned tag,
                           int bx0, int by0, int bx1, int by1, F pixel)
 {
     const int w = have ? bx1 - bx0 + 1 : 0, h = have ? by1 - by0 + 1 : 0;
     const bool big = have && (long long)w * h > RASTER_BIG;
+    STri mine;
+    if (have) {
+        raster_setup(clip, mine);
+        if (FLIP) raster_flip(mine);
+        mine.inv_D = INV_D ? 1.0 / mine.D : 0.0;
+    }
     if (have && !big) {
-        STri t;
-        raster_setup(clip, t);
-        if (FLIP) raster_flip(t);
-        if (INV_D) t.inv_D = 1.0 / t.D;
         for (int j = by0; j <= by1; j++)
-            for (int i = bx0; i <= bx1; i++) pixel(t, attr, tag, i, j);
+            for (int i = bx0; i <= bx1; i++) pixel(mine, attr, tag, i, j);
     }
     unsigned long long todo = __ballot(big);
+    if (todo == 0ull) return;  // wave-uniform
     const int lane = (int)__lane_id();
+    if (big) {
+        RasterRecord &r = pool.rec[lane];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            r.a[k] = mine.a[k]; r.b[k] = mine.b[k]; r.c[k] = mine.c[k]; r.z[k] = clip[k][2];
+#pragma unroll
+            for (int j = 0; j < 3; j++) r.attr[3 * k + j] = attr[k][j];
+        }
+        r.D = mine.D; r.inv_D = mine.inv_D; r.tag = tag;
+        r.bx0 = bx0; r.by0 = by0; r.w = (unsigned)w; r.samples = (unsigned)w * (unsigned)h;  // boxes hold fewer than 2^31 samples: faces and frames are at most 32768 wide
+        r.inv_w = 1.0f / (float)w;
+    }
+    raster_wave_fence();
     while (todo) {  // wave-uniform
         const int src = __builtin_ctzll(todo);
         todo &= todo - 1;
-        float c2[3][4], a2[3][4];
-#pragma unroll
-        for (int k = 0; k < 3; k++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) { c2[k][j] = readlane_f(clip[k][j], src); a2[k][j] = readlane_f(attr[k][j], src); }
-        const unsigned tag2 = (unsigned)__builtin_amdgcn_readlane((int)tag, src);
-        const int x0 = __builtin_amdgcn_readlane(bx0, src), y0 = __builtin_amdgcn_readlane(by0, src);
-        const int w2 = __builtin_amdgcn_readlane(w, src), h2 = __builtin_amdgcn_readlane(h, src);
+        const RasterRecord &r = pool.rec[src];
         STri t;
-        raster_setup(c2, t);
-        if (FLIP) raster_flip(t);
-        if (INV_D) t.inv_D = 1.0 / t.D;
-        // sample q = lane, lane + 64, ... of the box in row order; (ii, jj) advance by 64 samples without a
-        // division per step (boxes hold fewer than 2^31 samples: faces and frames are at most 32768 wide)
-        const unsigned uw = (unsigned)w2, total = uw * (unsigned)h2;
-        const unsigned step_rows = 64u / uw, step_cols = 64u - step_rows * uw;
-        unsigned jj = (unsigned)lane / uw, ii = (unsigned)lane - jj * uw;
+        float a2[3][4];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            t.a[c] = r.a[c]; t.b[c] = r.b[c]; t.c[c] = r.c[c]; t.z[c] = r.z[c];
+#pragma unroll
+            for (int j = 0; j < 3; j++) a2[c][j] = r.attr[3 * c + j];
+            a2[c][3] = 0.0f;
+        }
+        t.D = r.D; t.inv_D = r.inv_D;
+        const unsigned tag2 = r.tag;
+        const int x0 = r.bx0, y0 = r.by0;
+        // sample q = lane, lane + 64, ... of the box in row order; (ii, jj) advance by 64 samples without a division per step
+        const unsigned uw = r.w, total = r.samples;
+        const unsigned step_rows = (unsigned)(64.0f * r.inv_w);  // 64 / uw: the product is exact or within 2^-18 of a quotient that is not whole
+        const unsigned step_cols = 64u - step_rows * uw;
+        unsigned jj = (unsigned)((float)lane * r.inv_w), ii = (unsigned)lane - jj * uw;
+        if ((int)ii < 0) { jj--; ii += uw; } else if (ii >= uw) { jj++; ii -= uw; }
         for (unsigned q = (unsigned)lane; q < total; q += 64u) {
             pixel(t, a2, tag2, x0 + (int)ii, y0 + (int)jj);
             ii += step_cols; jj += step_rows;
             if (ii >= uw) { ii -= uw; jj++; }
         }
     }
+    raster_wave_fence();
 }
 
 // A stride coprime to n, near n / golden ratio: consecutive lanes then take triangles far apart in the mesh.

@@ -59,7 +59,7 @@ VKR_DEV size_t depth_texel_index(int res, int i, int j, bool tiled)
 // through `have`: all lanes of a call target the same image).  POINT: world = corners' world positions
 // and the depth is point_shadow.frag's; otherwise the fixed-function z / w.
 template <bool POINT>
-VKR_DEV void shadow_raster(bool valid, const float (&clip)[3][4], const float (&world)[3][4], const float *light_pos, float inv_far, int res, bool tiled, float store_scale, float *img)
+VKR_DEV void shadow_raster(RasterPool &pool, bool valid, const float (&clip)[3][4], const float (&world)[3][4], const float *light_pos, float inv_far, int res, bool tiled, float store_scale, float *img)
 {
     int bx0 = 0, by0 = 0, bx1 = -1, by1 = -1;
     bool have = valid && !clip_reject(clip);
@@ -69,7 +69,7 @@ VKR_DEV void shadow_raster(bool valid, const float (&clip)[3][4], const float (&
         have = t.D > 0.0 && shadow_bbox(clip, res, bx0, by0, bx1, by1);  // front faces and degenerate triangles are culled
     }
     const double sc = 2.0 / (double)res;
-    raster_boxes<false, !POINT>(have, clip, world, 0u, bx0, by0, bx1, by1, [&](const STri &t, const float (&wp)[3][4], unsigned, int i, int j) {
+    raster_boxes<false, !POINT>(pool, have, clip, world, 0u, bx0, by0, bx1, by1, [&](const STri &t, const float (&wp)[3][4], unsigned, int i, int j) {
         const double xn = __builtin_fma((double)i + 0.5, sc, -1.0), yn = __builtin_fma((double)j + 0.5, sc, -1.0);
         const double e0 = s_edge(t, 0, xn, yn), e1 = s_edge(t, 1, xn, yn), e2 = s_edge(t, 2, xn, yn);
         const double s = (e0 + e1) + e2;
@@ -105,6 +105,8 @@ VKR_DEV void shadow_raster(bool valid, const float (&clip)[3][4], const float (&
 __global__ __launch_bounds__(VKR_PS_BLOCK) void point_shadow_kernel(const ShadowParams p)
 {
     __shared__ float s_m[6][16];
+    __shared__ RasterPool pools[VKR_PS_BLOCK / 64];
+    RasterPool &pool = pools[threadIdx.x >> 6];
     const int li = blockIdx.y;
     const float *lp = p.lights + (size_t)li * 23 + 16;
     const float eye[3] = {lp[0], lp[1], lp[2]};
@@ -128,13 +130,14 @@ __global__ __launch_bounds__(VKR_PS_BLOCK) void point_shadow_kernel(const Shadow
         float clip[3][4];
 #pragma unroll
         for (int k = 0; k < 3; k++) mat4_vec4(s_m[face], world[k], clip[k]);  // point_shadow.geom:20
-        shadow_raster<true>(valid, clip, world, eye, inv_far, p.res, p.tiled != 0, p.store_scale, p.out + ((size_t)li * 6 + face) * face_texels);
+        shadow_raster<true>(pool, valid, clip, world, eye, inv_far, p.res, p.tiled != 0, p.store_scale, p.out + ((size_t)li * 6 + face) * face_texels);
     }
 }
 
 __global__ __launch_bounds__(256) void dir_shadow_kernel(const ShadowParams p)
 {
     __shared__ float s_mvp[16];
+    __shared__ RasterPool pools[4];
     if (threadIdx.x < 16) s_mvp[threadIdx.x] = mat4_mul_elem(p.model, p.light_space, threadIdx.x >> 2, threadIdx.x & 3);  // depth.vert:13
     __syncthreads();
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256) void dir_shadow_kernel(const ShadowParams p)
             mat4_vec4(s_mvp, v4, clip[k]);
         }
     }
-    shadow_raster<false>(valid, clip, clip, nullptr, 0.0f, p.res, false, 1.0f, p.out);
+    shadow_raster<false>(pools[threadIdx.x >> 6], valid, clip, clip, nullptr, 0.0f, p.res, false, 1.0f, p.out);
 }
 
 __global__ __launch_bounds__(256) void fill_depth_kernel(float4 *out, size_t n4, float value)
