@@ -19,11 +19,3 @@ for _ in range(10):
 e1.record(); torch.cuda.synchronize()
 cubes, layout = run()
 print("point shadow pass ms", round(e0.elapsed_time(e1) / 10, 4), "covered", float((cubes < 25.0).float().mean()))
-import ctypes
-from vulkanrenderer_amd import _lib
-lib = _lib.load()
-if hasattr(lib, "vkr_experiment_raster_counts"):
-    out = (ctypes.c_uint64 * 4)()
-    lib.vkr_experiment_raster_counts(out, 1)
-    run(); lib.vkr_experiment_raster_counts(out, 1)
-    print("samples", out[0], "boxes", out[1], "wave iterations", out[2], "calls with boxes", out[3], "samples per box", out[0] / max(out[1], 1), "lanes busy", out[0] / max(out[2] * 64, 1))

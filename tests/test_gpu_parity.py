@@ -1154,6 +1154,76 @@ def test_dir_shadow_map_bit_exact(gpu, oracle):
     assert not bad.any(), f"{bad.sum()} of {bad.size} texels differ"
 
 
+def _sliver_soup(seed, n, centre_radius=(0.8, 3.0), spread=3.0):
+    """n triangles of every size from a thousandth of a sample to tens of samples, many of them far thinner than a
+    sample: the ones whose box of sample centres is empty or a single row or column."""
+    rng = np.random.default_rng(seed)
+    direction = rng.normal(size=(n, 3)); direction /= np.linalg.norm(direction, axis=1, keepdims=True)
+    centre = direction * rng.uniform(*centre_radius, size=(n, 1)) * np.array([spread / 3.0, 1.0, spread / 3.0])
+    size = 10.0 ** rng.uniform(-3.5, -0.3, size=(n, 1))
+    thin = 10.0 ** rng.uniform(-3.0, 0.0, size=(n, 1))
+    e1 = rng.normal(size=(n, 3)) * size
+    e2 = rng.normal(size=(n, 3)) * size * thin
+    verts = np.stack([centre, centre + e1, centre + e1 * rng.uniform(0, 1, size=(n, 1)) + e2], axis=1).reshape(-1, 3).astype(np.float32)
+    tris = np.arange(3 * n, dtype=np.int32).reshape(n, 3)
+    return verts, tris
+
+
+@pytest.mark.parametrize("res,tiled", [(64, False), (136, None)])
+def test_shadow_maps_of_slivers(gpu, oracle, res, tiled):
+    """Triangles thinner and smaller than a sample, around two lights and under the directional one.  The kernels walk
+    the box of sample centres a triangle's extent can hold (empty for many of these); the oracle walks that box with a
+    margin of two samples on every side, so equal bits also say that the tight boxes lose no sample."""
+    torch, P = _torch(), _passes()
+    verts, tris = _sliver_soup(5, 6000)
+    draws = [(verts, tris, np.eye(4))]
+    lights = synth.make_lights(np.random.default_rng(3), 2)
+    lights["position"][0] = (0.0, 0.0, 0.0)
+    lights["position"][1] = (0.3, -0.2, 0.25)
+    want = oracle.point_shadow_maps(draws, lights, res)
+    assert 0.01 < (want < 1.0).mean() < 0.9
+    dev_lights = torch.from_numpy(np.frombuffer(lights.tobytes(), dtype=np.uint8).copy()).to(gpu)
+    got, layout = P.point_shadow_maps(_device_draws(draws, gpu), dev_lights, len(lights), res, tiled=tiled)
+    got = got.cpu().numpy()
+    if tiled is not False:
+        j, i = np.meshgrid(np.arange(res), np.arange(res), indexing="ij")
+        index = (i >> 3) * (res * 8) + j * 8 + (i & 7)
+        got = got.reshape(len(lights), 6, -1)[:, :, index.ravel()].reshape(want.shape)
+        want = want * np.float32(25.0)
+    bad = got.view(np.uint32) != want.view(np.uint32)
+    assert not bad.any(), f"{bad.sum()} of {bad.size} texels differ, first at {np.argwhere(bad)[0]}"
+    ls = synth.default_scene_info()["light_space_matrix"]
+    want = oracle.dir_shadow_map(draws, ls, 200)
+    assert (want < 1.0).any()
+    got = P.dir_shadow_map(_device_draws(draws, gpu), ls, 200, gpu).cpu().numpy()
+    bad = got.view(np.uint32) != want.view(np.uint32)
+    assert not bad.any(), f"directional map: {bad.sum()} of {bad.size} texels differ"
+
+
+def test_dir_shadow_map_with_corners_on_sample_centres(gpu, oracle):
+    """Triangles whose corners project onto sample centres of the directional map (as closely as binary32 positions
+    allow): samples on the rim of a box of sample centres, from inside and from outside."""
+    torch, P = _torch(), _passes()
+    res = 96
+    ls = np.asarray(synth.default_scene_info()["light_space_matrix"], dtype=np.float64).reshape(4, 4)
+    inv = np.linalg.inv(ls)
+    rng = np.random.default_rng(8)
+    n = 1500
+    ij = rng.integers(4, res - 4, size=(n, 3, 2)) + rng.integers(-3, 4, size=(n, 1, 2))
+    ndc = (ij + 0.5) * (2.0 / res) - 1.0
+    z = rng.uniform(0.2, 0.8, size=(n, 3, 1))
+    clip = np.concatenate([ndc, z, np.ones((n, 3, 1))], axis=2)  # orthographic: w = 1
+    world = clip @ inv                                            # row-vector convention
+    verts = (world[..., :3] / world[..., 3:]).reshape(-1, 3).astype(np.float32)
+    tris = np.arange(3 * n, dtype=np.int32).reshape(n, 3)
+    draws = [(verts, tris, np.eye(4))]
+    want = oracle.dir_shadow_map(draws, ls.astype(np.float32).ravel(), res)
+    assert 0.05 < (want < 1.0).mean()
+    got = P.dir_shadow_map(_device_draws(draws, gpu), ls.astype(np.float32).ravel(), res, gpu).cpu().numpy()
+    bad = got.view(np.uint32) != want.view(np.uint32)
+    assert not bad.any(), f"{bad.sum()} of {bad.size} texels differ, first at {np.argwhere(bad)[0]}"
+
+
 def test_generated_shadow_maps_feed_the_shading_pass(gpu, oracle):
     """End to end: shadow maps made by the library from the scene mesh (tiled cubes straight from the pass)
     shade to the bits the oracle gets from its own maps."""
@@ -1259,6 +1329,23 @@ def test_gbuffer_bit_exact(gpu, oracle, w, h, row0, frame_rows):
     want = oracle.gbuffer(draws, scene, w, h, frame_rows, row0)
     covered = want[0][..., 3] != 0
     assert 0.2 < covered.mean() < 0.95
+    got = P.gbuffer(_gpass_device_draws(draws, gpu), scene, w, h, gpu, frame_rows, row0)
+    for name, g, wv in zip(("albedo", "normal", "arm", "position"), got, want):
+        assert_bits_equal(P.f16_bits(g), wv, f"G-buffer {name}")
+
+
+@pytest.mark.parametrize("w,h,row0,frame_rows", [(157, 41, 30, 108), (64, 200, 0, 200)])
+def test_gbuffer_of_slivers(gpu, oracle, w, h, row0, frame_rows):
+    """The geometry pass over triangles thinner and smaller than a pixel, on frames far from square (the box of
+    sample centres is taken on the frame's own width x rows grid) and on a strip of one."""
+    torch, P = _torch(), _passes()
+    verts, tris = _sliver_soup(12, 5000, centre_radius=(0.0, 1.5))
+    uv, nrm, tan = synth.mesh_attributes(verts, tris, uv_scale=0.5)
+    alb, nmap, arm = synth.make_material(np.random.default_rng(77), 32)
+    draws = [dict(positions=verts, texcoords=uv, normals=nrm, tangents=tan, triangles=tris, model=np.eye(4), albedo=alb, normal=nmap, arm=arm)]
+    scene = _camera_scene((2.0, 1.6, -4.0), aspect=w / frame_rows)
+    want = oracle.gbuffer(draws, scene, w, h, frame_rows, row0)
+    assert 0.02 < (want[0][..., 3] != 0).mean() < 0.95
     got = P.gbuffer(_gpass_device_draws(draws, gpu), scene, w, h, gpu, frame_rows, row0)
     for name, g, wv in zip(("albedo", "normal", "arm", "position"), got, want):
         assert_bits_equal(P.f16_bits(g), wv, f"G-buffer {name}")
