@@ -2,7 +2,7 @@
 shadowed point lights (the headline configuration: 3840x2160, 64 point lights with 1024^2 cube shadow
 maps + a 4096^2 directional PCF shadow map), plus the IBL precompute time.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 100 --warmup 10
     python bench.py --gpus 8                      # starts its own 8 ranks (one process per GPU, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
@@ -895,8 +895,8 @@ def main() -> None:
     global WIDTH, HEIGHT
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--width", type=int, default=WIDTH, help="frame width (default: the headline 3840)")
     ap.add_argument("--height", type=int, default=HEIGHT, help="frame rows, split over the GPUs (default: the headline 2160)")
     ap.add_argument("--lights", type=int, default=LIGHTS)
