@@ -266,6 +266,12 @@ typedef struct VkrGpassArgs {
     void *workspace; int64_t workspace_bytes;    /* device memory, at least vkr_gbuffer_workspace_bytes() */
 } VkrGpassArgs;
 VKR_EXPORT int64_t vkr_gbuffer_workspace_bytes(int32_t width, int32_t rows, int32_t n_draws);
+/* The size of a workspace that also holds one 256-byte record per triangle of the call's draws (the vertex shader's
+ * outputs at its corners and its edge functions).  Given at least this much, vkr_gbuffer shades every triangle's
+ * corners once and the resolve step reads the winner's record, where it otherwise re-runs gpass.vert three times per
+ * pixel: the same bits, the resolve step 2x faster.  No counterpart in the reference (its vertex shader runs per vertex
+ * in the pipeline).  -1 for arguments out of range. */
+VKR_EXPORT int64_t vkr_gbuffer_workspace_bytes_with_triangles(int32_t width, int32_t rows, int32_t n_draws, int64_t n_triangles);
 VKR_EXPORT int32_t vkr_gbuffer(const VkrGpassArgs *args, void *stream);
 
 /* vkr_gbuffer for callers that cannot allocate device memory (tight serving loops, harnesses that forbid

@@ -1351,6 +1351,20 @@ def test_gbuffer_of_slivers(gpu, oracle, w, h, row0, frame_rows):
         assert_bits_equal(P.f16_bits(g), wv, f"G-buffer {name}")
 
 
+def test_gbuffer_with_and_without_triangle_records(gpu):
+    """vkr_gbuffer with the larger workspace (corners shaded once per triangle, records read by the resolve step) and
+    with the smallest one (corners shaded per pixel): the same four images, bit for bit."""
+    torch, P = _torch(), _passes()
+    w, h = 200, 120
+    draws = _gpass_device_draws(_gpass_scene(w, h), gpu)
+    scene = _camera_scene((2.0, 1.6, -4.0), aspect=w / h)
+    with_records = P.gbuffer(draws, scene, w, h, gpu, triangle_records=True)
+    without = P.gbuffer(draws, scene, w, h, gpu, triangle_records=False)
+    assert (with_records[0][..., 3] != 0).float().mean() > 0.2
+    for name, a, b in zip(("albedo", "normal", "arm", "position"), with_records, without):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)), f"G-buffer {name} differs between the two forms"
+
+
 def test_gbuffer_draws_of_few_triangles(gpu, oracle):
     """Draws of 1, 2, 3, 5 and 12 triangles cut from the slab (the visibility kernel hands lane s the triangle
     s * stride mod n: the stride is 1 below four triangles and coprime to n above), overlapping each other, so that

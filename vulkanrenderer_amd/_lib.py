@@ -168,6 +168,7 @@ PROTOTYPES = {
     "vkr_gbuffer_static": [C.POINTER(GpassArgs), _vp],
     "vkr_skybox": [_vp, _i32, _i32, C.POINTER(SceneInfo), _i32, _i32, _i32, _i32, _vp, _vp],
     "vkr_gbuffer_workspace_bytes": [_i32, _i32, _i32],
+    "vkr_gbuffer_workspace_bytes_with_triangles": [_i32, _i32, _i32, C.c_int64],
     "vkr_dir_shadow_map": [C.POINTER(DirShadowArgs), _vp],
     "vkr_bloom_blur": [C.POINTER(BloomArgs), _vp],
     "vkr_postprocess": [_vp, _vp, _vp, _i32, _i32, _i32, _vp],
@@ -233,7 +234,7 @@ PROTOTYPES = {
 _lib = None
 
 
-RETURNS_INT64 = {"vkr_gbuffer_workspace_bytes", "vkr_ibl_irradiance_by_region_workspace_bytes",
+RETURNS_INT64 = {"vkr_gbuffer_workspace_bytes", "vkr_gbuffer_workspace_bytes_with_triangles", "vkr_ibl_irradiance_by_region_workspace_bytes",
                  "vkr_ibl_irradiance_by_region_rows_workspace_bytes", "vkr_env_footprint_tiles_bytes",
                  "vkr_cube_shadow_ranges_bytes", "vkr_shade_workspace_bytes"}
 

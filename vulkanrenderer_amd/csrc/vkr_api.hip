@@ -281,8 +281,19 @@ static int32_t run_geometry_pass(vkr_ctx *c, Frame &f)
         d.albedo = mat.albedo; d.normal = mat.normal; d.arm = mat.arm;
     }
     if (draws.size() > (size_t)GP_MAX_DRAWS) return fail(VKR_ERR_UNSUPPORTED, "more than %d draw calls in a frame", GP_MAX_DRAWS);
-    if (!c->gp_workspace) {
-        c->gp_workspace_bytes = vkr_gbuffer_workspace_bytes(c->cfg.width, c->cfg.height, GP_MAX_DRAWS);
+    // Room for a record per triangle as well, so that the corners are shaded once per triangle.  The workspace grows when
+    // a frame brings more triangles than any before it (the frames in flight are waited for first: they use it).
+    int64_t triangles = 0;
+    for (const VkrGpassDraw &d : draws) triangles += d.n_tris;
+    const int64_t wanted = vkr_gbuffer_workspace_bytes_with_triangles(c->cfg.width, c->cfg.height, GP_MAX_DRAWS, triangles);
+    if (wanted < 0) return fail(VKR_ERR_UNSUPPORTED, "too many triangles in a frame");
+    if (!c->gp_workspace || c->gp_workspace_bytes < wanted) {
+        if (c->gp_workspace) {
+            VKR_HIP_CHECK(hipStreamSynchronize(c->stream));
+            (void)hipFree(c->gp_workspace);
+            c->gp_workspace = nullptr;
+        }
+        c->gp_workspace_bytes = wanted + wanted / 4;  // headroom: a scene that grows a little does not reallocate every frame
         VKR_HIP_CHECK(hipMalloc(&c->gp_workspace, (size_t)c->gp_workspace_bytes));
     }
     VkrGpassArgs a;

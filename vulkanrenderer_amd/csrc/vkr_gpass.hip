@@ -53,9 +53,15 @@ struct GpassParams {
     int width, rows, frame_rows, row0;
     unsigned long long *vis;
     uint2 *albedo, *normal, *arm, *position;
+    struct GpTriRecord *tri_records;  // one per triangle in submission order, or null: the resolve step shades the corners per pixel
 };
 
 struct GpVertex { float pos[4], uv[2], tbn[9], clip[4]; };
+
+// What the resolve step needs of a triangle: the edge functions of the flipped (front-facing) triangle and the
+// vertex shader's outputs at its three corners.
+struct alignas(16) GpTriRecord { double a[3], b[3], c[3]; float pos[3][4], uv[3][2], tbn[3][9], pad; };
+static_assert(sizeof(GpTriRecord) == 256, "sixteen 16-byte loads per record");
 
 // gpass.vert:24-35
 VKR_DEV void gpass_vertex(const VkrGpassDraw &d, const float *vp, unsigned i, GpVertex &o, bool attributes)
@@ -79,6 +85,37 @@ VKR_DEV void gpass_vertex(const VkrGpassDraw &d, const float *vp, unsigned i, Gp
     o.tbn[0] = T.x; o.tbn[1] = T.y; o.tbn[2] = T.z;
     o.tbn[3] = B.x; o.tbn[4] = B.y; o.tbn[5] = B.z;
     o.tbn[6] = N.x; o.tbn[7] = N.y; o.tbn[8] = N.z;
+}
+
+// The records of one draw's triangles: gpass.vert at the three corners and the set-up the resolve step would
+// otherwise redo for every pixel (the same functions on the same inputs, so the same bits).
+__global__ __launch_bounds__(256) void gpass_triangle_kernel(const GpassParams p)
+{
+    const VkrGpassDraw &d = p.draws[p.draw];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= d.n_tris) return;
+    GpVertex v[3];
+    float clip[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        gpass_vertex(d, p.vp, d.indices[3 * t + k], v[k], true);
+#pragma unroll
+        for (int j = 0; j < 4; j++) clip[k][j] = v[k].clip[j];
+    }
+    STri tr;
+    raster_setup(clip, tr);
+    raster_flip(tr);
+    GpTriRecord &r = p.tri_records[p.tri_base + (unsigned)t];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        r.a[k] = tr.a[k]; r.b[k] = tr.b[k]; r.c[k] = tr.c[k];
+#pragma unroll
+        for (int j = 0; j < 4; j++) r.pos[k][j] = v[k].pos[j];
+        r.uv[k][0] = v[k].uv[0]; r.uv[k][1] = v[k].uv[1];
+#pragma unroll
+        for (int j = 0; j < 9; j++) r.tbn[k][j] = v[k].tbn[j];
+    }
+    r.pad = 0.0f;
 }
 
 __global__ __launch_bounds__(256) void gpass_visibility_kernel(const GpassParams p)
@@ -126,8 +163,9 @@ __global__ __launch_bounds__(256) void gpass_visibility_kernel(const GpassParams
     });
 }
 
-// textureSampler on a single-level RGBA8 image: LINEAR, REPEAT; srgb: r, g, b are decoded before filtering
-VKR_DEV void tex2d_rgba8(const VkrTexture &t, bool srgb, float s, float tt, float (&o)[4])
+// textureSampler on a single-level RGBA8 image: LINEAR, REPEAT; srgb: r, g, b are decoded before filtering through
+// srgb_lut, the workgroup's copy of g_gp_srgb in LDS
+VKR_DEV void tex2d_rgba8(const VkrTexture &t, bool srgb, float s, float tt, const float *srgb_lut, float (&o)[4])
 {
     const int w = t.width, h = t.height;
     const float x = s * (float)w - 0.5f, y = tt * (float)h - 0.5f;
@@ -142,14 +180,19 @@ VKR_DEV void tex2d_rgba8(const VkrTexture &t, bool srgb, float s, float tt, floa
     for (int c = 0; c < 4; c++) {
         const uint32_t b00 = (p00 >> (8 * c)) & 0xFF, b10 = (p10 >> (8 * c)) & 0xFF, b01 = (p01 >> (8 * c)) & 0xFF, b11 = (p11 >> (8 * c)) & 0xFF;
         float a, b, cc, d;
-        if (srgb && c < 3) { a = g_gp_srgb[b00]; b = g_gp_srgb[b10]; cc = g_gp_srgb[b01]; d = g_gp_srgb[b11]; }
+        if (srgb && c < 3) { a = srgb_lut[b00]; b = srgb_lut[b10]; cc = srgb_lut[b01]; d = srgb_lut[b11]; }
         else { a = (float)b00 * (1.0f / 255.0f); b = (float)b10 * (1.0f / 255.0f); cc = (float)b01 * (1.0f / 255.0f); d = (float)b11 * (1.0f / 255.0f); }
         o[c] = fma_(w11, d, fma_(w01, cc, fma_(w10, b, w00 * a)));
     }
 }
 
+// RECORDS: the winner's corners and edge functions are read from p.tri_records instead of being recomputed per pixel.
+template <bool RECORDS>
 __global__ __launch_bounds__(256) void gpass_resolve_kernel(const GpassParams p)
 {
+    __shared__ float s_srgb[256];
+    s_srgb[threadIdx.x] = g_gp_srgb[threadIdx.x];
+    __syncthreads();
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= p.width || y >= p.rows) return;
     const size_t px = (size_t)y * p.width + x;
@@ -165,20 +208,36 @@ __global__ __launch_bounds__(256) void gpass_resolve_kernel(const GpassParams p)
     while (di + 1 < p.n_draws && id - base >= (unsigned)p.draws[di].n_tris) { base += (unsigned)p.draws[di].n_tris; di++; }
     const VkrGpassDraw &d = p.draws[di];
     const unsigned t = id - base;
-    GpVertex v[3];
-    float clip[3][4];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        gpass_vertex(d, p.vp, d.indices[3 * t + k], v[k], true);
-#pragma unroll
-        for (int j = 0; j < 4; j++) clip[k][j] = v[k].clip[j];
-    }
-    STri tr;
-    raster_setup(clip, tr);
-    raster_flip(tr);
     const double sx = 2.0 / (double)p.width, sy = 2.0 / (double)p.frame_rows;
     const double xn = __builtin_fma((double)x + 0.5, sx, -1.0), yn = __builtin_fma((double)(p.row0 + y) + 0.5, sy, -1.0);
-    const double e0 = s_edge(tr, 0, xn, yn), e1 = s_edge(tr, 1, xn, yn), e2 = s_edge(tr, 2, xn, yn);
+    GpVertex v[3];
+    double e0, e1, e2;
+    if (RECORDS) {
+        const GpTriRecord &r = p.tri_records[id];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[k].pos[j] = r.pos[k][j];
+            v[k].uv[0] = r.uv[k][0]; v[k].uv[1] = r.uv[k][1];
+#pragma unroll
+            for (int j = 0; j < 9; j++) v[k].tbn[j] = r.tbn[k][j];
+        }
+        e0 = __builtin_fma(r.a[0], xn, __builtin_fma(r.b[0], yn, r.c[0]));
+        e1 = __builtin_fma(r.a[1], xn, __builtin_fma(r.b[1], yn, r.c[1]));
+        e2 = __builtin_fma(r.a[2], xn, __builtin_fma(r.b[2], yn, r.c[2]));
+    } else {
+        float clip[3][4];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            gpass_vertex(d, p.vp, d.indices[3 * t + k], v[k], true);
+#pragma unroll
+            for (int j = 0; j < 4; j++) clip[k][j] = v[k].clip[j];
+        }
+        STri tr;
+        raster_setup(clip, tr);
+        raster_flip(tr);
+        e0 = s_edge(tr, 0, xn, yn); e1 = s_edge(tr, 1, xn, yn); e2 = s_edge(tr, 2, xn, yn);
+    }
     // attributes are interpolated in binary32, as in the shadow pass: the binary64 edge values rounded to binary32 are the
     // perspective-correct weights
     const float f0 = (float)e0, f1 = (float)e1, f2 = (float)e2;
@@ -192,9 +251,9 @@ __global__ __launch_bounds__(256) void gpass_resolve_kernel(const GpassParams p)
     for (int k = 0; k < 9; k++) tbn[k] = lerp(v[0].tbn[k], v[1].tbn[k], v[2].tbn[k]);
     // gpass.frag:18-28
     float alb[4], nm[4], arm[4];
-    tex2d_rgba8(d.albedo, true, u, vv, alb);
-    tex2d_rgba8(d.normal, false, u, vv, nm);
-    tex2d_rgba8(d.arm, true, u, vv, arm);
+    tex2d_rgba8(d.albedo, true, u, vv, s_srgb, alb);
+    tex2d_rgba8(d.normal, false, u, vv, s_srgb, nm);
+    tex2d_rgba8(d.arm, true, u, vv, s_srgb, arm);
     const f3 n = normalize3(mk3(fma_(nm[0], 2.0f, -1.0f), fma_(nm[1], 2.0f, -1.0f), fma_(nm[2], 2.0f, -1.0f)));
     const float wn0 = fma_(tbn[6], n.z, fma_(tbn[3], n.y, tbn[0] * n.x));
     const float wn1 = fma_(tbn[7], n.z, fma_(tbn[4], n.y, tbn[1] * n.x));
@@ -250,6 +309,13 @@ extern "C" int64_t vkr_gbuffer_workspace_bytes(int32_t width, int32_t rows, int3
     return (int64_t)width * rows * 8 + (int64_t)n_draws * (int64_t)sizeof(VkrGpassDraw) + 256;
 }
 
+extern "C" int64_t vkr_gbuffer_workspace_bytes_with_triangles(int32_t width, int32_t rows, int32_t n_draws, int64_t n_triangles)
+{
+    const int64_t base = vkr_gbuffer_workspace_bytes(width, rows, n_draws);
+    if (base < 0 || n_triangles < 0 || n_triangles >= (1ll << 32) - 1) return -1;
+    return ((base + 255) & ~(int64_t)255) + n_triangles * (int64_t)sizeof(vkr::GpTriRecord);
+}
+
 namespace vkr {
 
 // Checks everything about a geometry-pass call except where its scratch memory comes from.
@@ -274,9 +340,10 @@ static int32_t check_gbuffer(const char *who, const VkrGpassArgs *a)
 
 // The launches of the geometry pass.  `vis` (one 64-bit key per pixel) and `dev_draws` (room for the draw
 // records) are device scratch memory; every key is reset here, so the scratch may hold anything on entry.
-static int32_t launch_gbuffer(const char *who, const VkrGpassArgs *a, unsigned long long *vis, VkrGpassDraw *dev_draws, void *stream)
+static int32_t launch_gbuffer(const char *who, const VkrGpassArgs *a, unsigned long long *vis, VkrGpassDraw *dev_draws, GpTriRecord *tri_records, void *stream)
 {
     GpassParams p;
+    p.tri_records = tri_records;
     const size_t npx = (size_t)a->width * a->rows;
     p.vis = vis;
     p.draws = dev_draws; p.n_draws = a->n_draws;
@@ -297,10 +364,13 @@ static int32_t launch_gbuffer(const char *who, const VkrGpassArgs *a, unsigned l
             p.draw = d; p.tri_base = base;
             p.scatter_stride = scatter_stride_for((unsigned)a->draws[d].n_tris);
             hipLaunchKernelGGL(gpass_visibility_kernel, dim3((unsigned)((a->draws[d].n_tris + 255) / 256)), dim3(256), 0, as_stream(stream), p);
+            if (tri_records) hipLaunchKernelGGL(gpass_triangle_kernel, dim3((unsigned)((a->draws[d].n_tris + 255) / 256)), dim3(256), 0, as_stream(stream), p);
         }
         base += (unsigned)a->draws[d].n_tris;
     }
-    hipLaunchKernelGGL(gpass_resolve_kernel, dim3((unsigned)((a->width + 63) / 64), (unsigned)((a->rows + 3) / 4)), dim3(256), 0, as_stream(stream), p);
+    const dim3 grid((unsigned)((a->width + 63) / 64), (unsigned)((a->rows + 3) / 4));
+    if (tri_records) hipLaunchKernelGGL(gpass_resolve_kernel<true>, grid, dim3(256), 0, as_stream(stream), p);
+    else hipLaunchKernelGGL(gpass_resolve_kernel<false>, grid, dim3(256), 0, as_stream(stream), p);
     return launch_status(who);
 }
 
@@ -341,7 +411,14 @@ extern "C" int32_t vkr_gbuffer(const VkrGpassArgs *a, void *stream)
     if ((rc = ensure_srgb_table()) != VKR_OK) return rc;
     const size_t npx = (size_t)a->width * a->rows;
     VkrGpassDraw *dev_draws = (VkrGpassDraw *)((char *)a->workspace + ((npx * 8 + 255) & ~(size_t)255));
-    return launch_gbuffer("vkr_gbuffer", a, (unsigned long long *)a->workspace, dev_draws, stream);
+    // a workspace of vkr_gbuffer_workspace_bytes_with_triangles() also has room for a record per triangle
+    int64_t total_tris = 0;
+    for (int d = 0; d < a->n_draws; d++) total_tris += a->draws[d].n_tris;
+    const int64_t with_records = vkr_gbuffer_workspace_bytes_with_triangles(a->width, a->rows, a->n_draws, total_tris);
+    GpTriRecord *tri_records = nullptr;
+    if (total_tris > 0 && with_records > 0 && a->workspace_bytes >= with_records)
+        tri_records = (GpTriRecord *)((char *)a->workspace + (((size_t)need + 255) & ~(size_t)255));
+    return launch_gbuffer("vkr_gbuffer", a, (unsigned long long *)a->workspace, dev_draws, tri_records, stream);
 }
 
 extern "C" int32_t vkr_gbuffer_static(const VkrGpassArgs *a, void *stream)
@@ -357,7 +434,7 @@ extern "C" int32_t vkr_gbuffer_static(const VkrGpassArgs *a, void *stream)
     if ((rc = ensure_srgb_table()) != VKR_OK) return rc;
     void *base = nullptr;
     if ((rc = static_scratch(&base)) != VKR_OK) return rc;
-    return launch_gbuffer("vkr_gbuffer_static", a, (unsigned long long *)base, (VkrGpassDraw *)((char *)base + GPS_KEY_BYTES), stream);
+    return launch_gbuffer("vkr_gbuffer_static", a, (unsigned long long *)base, (VkrGpassDraw *)((char *)base + GPS_KEY_BYTES), nullptr, stream);
 }
 
 extern "C" int32_t vkr_skybox(const void *env, int32_t env_n, int32_t env_layout, const VkrSceneInfo *scene,

@@ -170,10 +170,13 @@ def dir_shadow_map(draws, light_space, res: int, device) -> torch.Tensor:
     return out
 
 
-def gbuffer(draws, scene: np.ndarray, width: int, rows: int, device, frame_rows: int | None = None, row0: int = 0):
+def gbuffer(draws, scene: np.ndarray, width: int, rows: int, device, frame_rows: int | None = None, row0: int = 0,
+            triangle_records: bool = True):
     """The geometry pass: (albedo, normal, arm, position) float16 [rows, width, 4].  draws: list of dicts of
     device tensors -- positions [n,3], texcoords [n,2], normals [n,3], tangents [n,3] float32, triangles [m,3]
-    int32, the RGBA8 images albedo / normal / arm [h,w,4] uint8 -- and `model` (16 floats)."""
+    int32, the RGBA8 images albedo / normal / arm [h,w,4] uint8 -- and `model` (16 floats).
+    `triangle_records`: give the call the larger workspace with which it shades every triangle's corners once
+    (False: the smallest workspace; the resolve step then shades the corners per pixel -- same image)."""
     lib = _lib.load()
     arr = (_lib.GpassDraw * len(draws))()
     for k, d in enumerate(draws):
@@ -191,7 +194,11 @@ def gbuffer(draws, scene: np.ndarray, width: int, rows: int, device, frame_rows:
             tex = getattr(arr[k], name)
             tex.rgba8, tex.width, tex.height = t.data_ptr(), t.shape[1], t.shape[0]
     out = [torch.empty((rows, width, 4), dtype=torch.float16, device=device) for _ in range(4)]
-    need = lib.vkr_gbuffer_workspace_bytes(width, rows, len(draws))
+    # with room for a record per triangle: the corners are shaded once per triangle instead of three times per pixel
+    if triangle_records:
+        need = lib.vkr_gbuffer_workspace_bytes_with_triangles(width, rows, len(draws), sum(int(d["triangles"].shape[0]) for d in draws))
+    else:
+        need = lib.vkr_gbuffer_workspace_bytes(width, rows, len(draws))
     workspace = torch.empty(need, dtype=torch.uint8, device=device)
     a = _lib.GpassArgs()
     a.draws, a.n_draws = arr, len(draws)
