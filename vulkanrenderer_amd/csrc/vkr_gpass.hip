@@ -118,6 +118,11 @@ __global__ __launch_bounds__(256) void gpass_triangle_kernel(const GpassParams p
     r.pad = 0.0f;
 }
 
+#ifndef VKR_VIS_SPREAD
+#define VKR_VIS_SPREAD 4
+#endif
+static constexpr int VIS_SPREAD = VKR_VIS_SPREAD;
+
 __global__ __launch_bounds__(256) void gpass_visibility_kernel(const GpassParams p)
 {
     __shared__ RasterPool pools[4];
@@ -126,8 +131,11 @@ __global__ __launch_bounds__(256) void gpass_visibility_kernel(const GpassParams
     // triangles per wave the few waves that own the triangles next to the camera would run long after the rest
     // (there is about one wave per SIMD).  Triangle s * stride mod n for lane s spreads every wave over the mesh;
     // the stride is coprime to n, so every triangle is taken exactly once.
-    const int s = blockIdx.x * 256 + threadIdx.x;
-    bool have = s < d.n_tris;  // lanes past the end stay: the wave shares large triangles
+    // Only every VIS_SPREAD-th lane brings a triangle: with a lane each, a 66 000-triangle mesh is one wave per SIMD,
+    // nothing hides the latency of a wave's binary64 chains and atomics, and the vector ALUs are 14 % busy; the samples
+    // of all but the smallest boxes are walked by the whole wave anyway.
+    const int g = blockIdx.x * 256 + threadIdx.x, s = g / VIS_SPREAD;
+    bool have = g % VIS_SPREAD == 0 && s < d.n_tris;  // the other lanes stay: the wave shares large triangles
     const int t = have ? (int)(((unsigned long long)s * p.scatter_stride) % (unsigned)d.n_tris) : 0;
     float clip[3][4] = {};
     int bx0 = 0, by0 = 0, bx1 = -1, by1 = -1;
@@ -363,7 +371,7 @@ static int32_t launch_gbuffer(const char *who, const VkrGpassArgs *a, unsigned l
         if (a->draws[d].n_tris > 0) {
             p.draw = d; p.tri_base = base;
             p.scatter_stride = scatter_stride_for((unsigned)a->draws[d].n_tris);
-            hipLaunchKernelGGL(gpass_visibility_kernel, dim3((unsigned)((a->draws[d].n_tris + 255) / 256)), dim3(256), 0, as_stream(stream), p);
+            hipLaunchKernelGGL(gpass_visibility_kernel, dim3((unsigned)(((size_t)a->draws[d].n_tris * VIS_SPREAD + 255) / 256)), dim3(256), 0, as_stream(stream), p);
             if (tri_records) hipLaunchKernelGGL(gpass_triangle_kernel, dim3((unsigned)((a->draws[d].n_tris + 255) / 256)), dim3(256), 0, as_stream(stream), p);
         }
         base += (unsigned)a->draws[d].n_tris;
